@@ -1,0 +1,129 @@
+/*
+ * mpcqp.h -- C ABI of the MI355X-native batched QP engine (libmpcqp.so).
+ *
+ * Drop-in boundary.  The reference has no FFI; its seam is the C++ class CuCaQP
+ * (reference include/optimal_control_problem/sqp_solver/CuCaQP.h:27-102), driven from one place in the
+ * order setDimension -> settings -> [ setSystem(P,q,A,l,u) -> initSolver -> solve -> getSolution ]
+ * (reference src/sqp_solver/SQPOptimizationSolver.cpp:80-85,155-167).  Each entry point below names the
+ * CuCaQP member(s) it replaces.  One handle owns one batch of QPs that share a sparsity pattern (the
+ * reference's batch is 1); distinct handles are independent (one per GPU when sharding a batch).
+ *
+ * Plain C: no exceptions cross the ABI, integer status codes, caller owns every I/O buffer, the library
+ * owns its device workspace.  A handle is not thread-safe (neither is CuCaQP).
+ */
+#ifndef MPCQP_H
+#define MPCQP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCQP_OK 0
+#define MPCQP_ERR_ARG 1       /* bad dimensions / null pointers / malformed CSC   (CuCaQP.cpp:23-27,49-52) */
+#define MPCQP_ERR_HIP 2       /* a HIP runtime call failed; mpcqp_strerror() carries the HIP message        */
+#define MPCQP_ERR_NO_GPU 3    /* no gfx950 device / code object missing: the product path has no CPU fallback */
+#define MPCQP_ERR_STATE 4     /* call order violated (solve before update, ...)   (CuCaQP.cpp:199-203)      */
+#define MPCQP_ERR_LIMIT 5     /* problem does not fit the kernel's on-chip budget                          */
+
+/* per-QP solver status, numerically identical to OSQP 1.0's osqp_status_type */
+#define MPCQP_SOLVED 1
+#define MPCQP_SOLVED_INACCURATE 2
+#define MPCQP_PRIMAL_INFEASIBLE 3
+#define MPCQP_PRIMAL_INFEASIBLE_INACCURATE 4
+#define MPCQP_DUAL_INFEASIBLE 5
+#define MPCQP_DUAL_INFEASIBLE_INACCURATE 6
+#define MPCQP_MAX_ITER_REACHED 7
+#define MPCQP_NON_CVX 9
+#define MPCQP_UNSOLVED 11
+
+#define MPCQP_MEM_HOST 0      /* pointer is host memory (pageable or pinned) */
+#define MPCQP_MEM_DEVICE 1    /* pointer is device memory on the handle's GPU */
+
+/* Replaces CuCaQP::setVerbosity/setWarmStart/setAbsoluteTolerance/setRelativeTolerance/setMaxIteration
+ * (reference src/sqp_solver/CuCaQP.cpp:163-181).  Defaults = OSQP defaults with the values the reference
+ * fixes at src/sqp_solver/SQPOptimizationSolver.cpp:81-85 (eps_abs = eps_rel = 1e-3, max_iter = 10000). */
+typedef struct mpcqp_settings {
+  double rho;                    /* 0.1   */
+  double sigma;                  /* 1e-6  */
+  double alpha;                  /* 1.6   */
+  double eps_abs;                /* 1e-3  */
+  double eps_rel;                /* 1e-3  */
+  double eps_prim_inf;           /* 1e-4  */
+  double eps_dual_inf;           /* 1e-4  */
+  double adaptive_rho_tolerance; /* 5     */
+  int max_iter;                  /* 10000 */
+  int check_termination;         /* 25    */
+  int scaling;                   /* 10 Ruiz passes */
+  int adaptive_rho;              /* 1     */
+  int adaptive_rho_interval;     /* 0 -> 4 * check_termination (deterministic; OSQP's wall-clock rule is not reproducible) */
+  int scaled_termination;        /* 0     */
+  int warm_start;                /* 0 = cold start from x = z = y = 0, which is what the reference does
+                                    because CuCaQP::setSystem clears the solver (CuCaQP.cpp:271-288) */
+  int device;                    /* HIP device ordinal, -1 = current device */
+} mpcqp_settings;
+
+typedef struct mpcqp_handle mpcqp_handle;
+
+void mpcqp_default_settings(mpcqp_settings *s);
+
+/* Replaces CuCaQP::CuCaQP + setDimension (CuCaQP.cpp:5-41) and the pattern-dependent part of initSolver
+ * (CuCaQP.cpp:183-197): n variables, m constraint rows, `batch` QP instances sharing one sparsity.
+ * P is CSC n x n -- either triangle or both (CasADi hands the reference both triangles; like OsqpEigen,
+ * only entries with row <= col are used); A is CSC m x n.  Index arrays are copied. */
+int mpcqp_create(int n, int m, int batch,
+                 const int *P_colptr, const int *P_rowidx,
+                 const int *A_colptr, const int *A_rowidx,
+                 const mpcqp_settings *settings, mpcqp_handle **out);
+
+/* Replaces CuCaQP::setSystem -> setHessianMatrix/setGradient/setLinearConstraintsMatrix/setLowerBound/
+ * setUpperBound (CuCaQP.cpp:43-103,271-288), argument order P,q,A,l,u as at CuCaQP.cpp:283-287.
+ * Value arrays are instance-major: QP b reads P + b*strideP (in doubles) ... ; stride 0 shares one array
+ * across the batch.  mem = MPCQP_MEM_HOST: values are copied (caller may free at once, as with CuCaQP,
+ * which copies into its members CuCaQP.h:83-87).  mem = MPCQP_MEM_DEVICE: pointers are borrowed until
+ * the next mpcqp_solve on this handle has completed. */
+int mpcqp_update(mpcqp_handle *h,
+                 const double *P, long strideP, const double *q, long strideq,
+                 const double *A, long strideA, const double *l, long stridel,
+                 const double *u, long strideu, int mem);
+
+/* The (unused, private) CuCaQP::update* fast path made real (CuCaQP.cpp:106-161): primal/dual start
+ * x0 [batch*n], y0 [batch*m]; honoured by the next solve when settings.warm_start != 0. */
+int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int mem);
+
+/* Replaces CuCaQP::initSolver + CuCaQP::solve (CuCaQP.cpp:183-211): per QP, Ruiz scaling, KKT
+ * factorisation and the ADMM loop run in one launch on `stream` (a hipStream_t, NULL = default stream).
+ * Asynchronous: returns after the launch; results are ordered on `stream`. */
+int mpcqp_solve(mpcqp_handle *h, void *stream);
+
+/* Replaces CuCaQP::getSolution / getSolutionAsDM (CuCaQP.cpp:213-224), and additionally surfaces what the
+ * reference drops: duals y, row activities z, per-QP status, iteration count and
+ * info[4] = {objective, primal residual, dual residual, final rho}.  Any output pointer may be NULL.
+ * Copies are issued on the stream of the last solve; with MPCQP_MEM_HOST the call returns after they
+ * have completed. */
+int mpcqp_get(mpcqp_handle *h, double *x, double *y, double *z, int *status, int *iters, double *info, int mem);
+
+int mpcqp_sync(mpcqp_handle *h);                 /* wait for the last solve / copies */
+void mpcqp_destroy(mpcqp_handle *h);             /* replaces CuCaQP::~CuCaQP (CuCaQP.cpp:16-21) */
+const char *mpcqp_strerror(int code);            /* replaces the std::cerr messages of CuCaQP.cpp */
+
+/* Measurement hooks (no reference counterpart; the reference times setSystem+initSolver+solve with
+ * std::chrono, SQPOptimizationSolver.cpp:153-160).  Duration of the last solve kernel from HIP events
+ * recorded around the launch on its stream (waits for the kernel). */
+int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms);
+/* info[0..15]: n, m, batch, npad, mpad, n_blocks(n/16), L_blocks, lds_bytes_per_qp, workspace_bytes_per_qp,
+ * ordering(0 natural,1 hubs-last), nnzP_triu, nnzA, T_blocks, factor_ops, ell_slots_total, reserved */
+int mpcqp_plan_info(const mpcqp_handle *h, long *info16);
+
+/* Replaces CuCaQP::printSolverData (CuCaQP.cpp:226-269): copies the scaled problem data the kernel holds
+ * for instance b back to the host (D [n], E [m], c; any pointer may be NULL). */
+int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c);
+
+/* Kernel self-test of the 16x16 block primitives (MFMA f64 A*B^T, Cholesky+inverse) on caller data:
+ * A, B, C are row-major 16x16; out_gemm = C - A*B^T; out_linv = inverse of chol(S) for SPD S (lower). */
+int mpcqp_debug_blockops(const double *A, const double *B, const double *C, const double *S,
+                         double *out_gemm, double *out_linv, int *potrf_fail);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,150 @@
+"""BatchQP: thin object wrapper over the C ABI (include/mpcqp.h) for a batch of QPs sharing a sparsity.
+
+Accepts NumPy arrays (host memory, copied by the library like CuCaQP copies into its members,
+reference include/optimal_control_problem/sqp_solver/CuCaQP.h:83-87) or torch CUDA tensors (device
+memory, borrowed; torch is only the allocator/stream provider here)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _is_torch(a):
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
+def _ptr_stride(a, width, batch, name):
+    """-> (pointer, stride_in_doubles, mem, keepalive)"""
+    if a is None:
+        return None, 0, None, None
+    if _is_torch(a):
+        import torch
+        if a.dtype != torch.float64 or not a.is_contiguous():
+            raise ValueError("%s: torch tensor must be contiguous float64" % name)
+        shape = tuple(a.shape)
+        mem = _lib.MEM_DEVICE if a.is_cuda else _lib.MEM_HOST
+        ptr = a.data_ptr()
+        keep = a
+    else:
+        keep = np.ascontiguousarray(a, dtype=np.float64)
+        shape = keep.shape
+        mem = _lib.MEM_HOST
+        ptr = keep.ctypes.data
+    if len(shape) == 1:
+        if shape[0] != width:
+            raise ValueError("%s: expected %d values, got %d (dimension mismatch)" % (name, width, shape[0]))
+        return ptr, 0, mem, keep
+    if shape != (batch, width):
+        raise ValueError("%s: expected shape (%d, %d), got %s (dimension mismatch)" % (name, batch, width, shape))
+    return ptr, width, mem, keep
+
+
+class BatchQP:
+    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, **kw):
+        self.n, self.m, self.batch = int(n), int(m), int(batch)
+        self.Pp = np.ascontiguousarray(Pp, dtype=np.int32); self.Pi = np.ascontiguousarray(Pi, dtype=np.int32)
+        self.Ap = np.ascontiguousarray(Ap, dtype=np.int32); self.Ai = np.ascontiguousarray(Ai, dtype=np.int32)
+        if len(self.Pp) != self.n + 1 or len(self.Ap) != self.n + 1:
+            raise ValueError("colptr arrays must have n + 1 entries")
+        self.settings = settings if settings is not None else _lib.default_settings(**kw)
+        self._h = C.c_void_p()
+        self._keep = []
+        L = _lib.lib()
+        _lib.check(L.mpcqp_create(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
+                                  self.Ap.ctypes.data, self.Ai.ctypes.data, C.byref(self.settings), C.byref(self._h)))
+
+    @property
+    def nnzP(self):
+        return int(self.Pp[-1])
+
+    @property
+    def nnzA(self):
+        return int(self.Ap[-1])
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().mpcqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, P, q, A, l, u):
+        B = self.batch
+        items = [_ptr_stride(P, self.nnzP, B, "P"), _ptr_stride(q, self.n, B, "q"), _ptr_stride(A, self.nnzA, B, "A"),
+                 _ptr_stride(l, self.m, B, "l"), _ptr_stride(u, self.m, B, "u")]
+        mems = {it[2] for it in items if it[2] is not None}
+        if len(mems) != 1:
+            raise ValueError("all of P, q, A, l, u must live in the same memory space")
+        self._keep = [it[3] for it in items]
+        args = []
+        for ptr, stride, _, _ in items:
+            args += [ptr, stride]
+        _lib.check(_lib.lib().mpcqp_update(self._h, *args, mems.pop()))
+
+    def warm_start(self, x0, y0):
+        px, _, memx, kx = _ptr_stride(x0, self.n, self.batch, "x0")
+        py, _, memy, ky = _ptr_stride(y0, self.m, self.batch, "y0")
+        if memx != memy:
+            raise ValueError("x0 and y0 must live in the same memory space")
+        self._keep_ws = (kx, ky)
+        _lib.check(_lib.lib().mpcqp_warm_start(self._h, px, py, memx))
+
+    def solve(self, stream=None):
+        _lib.check(_lib.lib().mpcqp_solve(self._h, stream))
+
+    def sync(self):
+        _lib.check(_lib.lib().mpcqp_sync(self._h))
+
+    def get(self, want=("x", "y", "z", "status", "iters", "info")):
+        B = self.batch
+        out = {}
+        if "x" in want: out["x"] = np.empty((B, self.n))
+        if "y" in want: out["y"] = np.empty((B, self.m))
+        if "z" in want: out["z"] = np.empty((B, self.m))
+        if "status" in want: out["status"] = np.empty(B, dtype=np.int32)
+        if "iters" in want: out["iters"] = np.empty(B, dtype=np.int32)
+        if "info" in want: out["info"] = np.empty((B, 4))
+        p = lambda k: out[k].ctypes.data if k in out else None
+        _lib.check(_lib.lib().mpcqp_get(self._h, p("x"), p("y"), p("z"), p("status"), p("iters"), p("info"), _lib.MEM_HOST))
+        if "info" in out:
+            info = out.pop("info")
+            out.update(obj=info[:, 0], prim_res=info[:, 1], dual_res=info[:, 2], rho=info[:, 3])
+        return out
+
+    def get_device(self, x=None, y=None, z=None, status=None, iters=None, info=None):
+        """Copy results into caller-owned torch CUDA tensors (device-to-device, on the solve stream)."""
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(_lib.lib().mpcqp_get(self._h, p(x), p(y), p(z), p(status), p(iters), p(info), _lib.MEM_DEVICE))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _lib.check(_lib.lib().mpcqp_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def plan_info(self):
+        a = np.zeros(16, dtype=np.int64)
+        _lib.check(_lib.lib().mpcqp_plan_info(self._h, a.ctypes.data))
+        keys = ["n", "m", "batch", "npad", "mpad", "n_blocks", "L_blocks", "lds_bytes", "workspace_bytes_per_qp",
+                "ordering", "nnzP_triu", "nnzA", "T_blocks", "factor_ops", "ell_slots", "reserved"]
+        return dict(zip(keys, a.tolist()))
+
+    def debug_scaling(self, b=0):
+        D = np.empty(self.n); E = np.empty(self.m); c = np.empty(1)
+        _lib.check(_lib.lib().mpcqp_debug_scaling(self._h, int(b), D.ctypes.data, E.ctypes.data, c.ctypes.data))
+        return D, E, float(c[0])
+
+
+def solve_local_system(ls, settings=None, **kw):
+    """Convenience: solve a models.LocalSystem batch on the GPU, return the result dict."""
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, settings, **kw)
+    try:
+        qp.update(ls.P, ls.q, ls.A, ls.l, ls.u)
+        qp.solve()
+        return qp.get()
+    finally:
+        qp.close()

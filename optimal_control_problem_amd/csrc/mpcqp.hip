@@ -1,0 +1,895 @@
+// mpcqp.hip -- MI355X (gfx950) batched OSQP-style ADMM: device kernels + the C ABI of include/mpcqp.h.
+//
+// Replaces, for a batch of QPs sharing one sparsity, what the reference does per QP on the host through
+// CuCaQP::setSystem -> initSolver -> solve -> getSolution (reference src/sqp_solver/CuCaQP.cpp:271-288,
+// 183-224), i.e. OSQP's osqp_setup + osqp_solve (external to the reference, see oracle/osqp_oracle.h).
+//
+// Execution model: ONE QP PER WAVEFRONT (64-thread workgroup, no inter-wave synchronisation at all).
+//   * ADMM iterates x, q, rhs [npad] and z, y, rho*z-y [mpad] live in LDS for the whole solve;
+//   * matrix data (scaled A in two ELL orientations, scaled P, the block Cholesky factor of
+//     M = P + sigma I + A' diag(rho) A in forward and transposed-backward stream order) lives in a per-QP
+//     HBM slab and is streamed with fully coalesced 512 B / 2 KiB wave loads;
+//   * the linear solve is a stream of 16x16 block mat-vecs: 4 lanes per row, quad-shuffle reduction;
+//   * the factorisation's block products (assembly of M, Schur updates, L_IJ = S_IJ Linv_JJ') are real dense
+//     16x16x16 GEMMs and run on the matrix cores (v_mfma_f64_16x16x4_f64); the 16x16 Cholesky + triangular
+//     inverse runs in LDS;
+//   * box projection, dual update and all residual norms are fused into the ELL sweeps and reduced with
+//     wavefront shuffles.
+// Numerics are fp64 throughout and follow oracle/osqp_oracle.c step by step (same scaling rule, rho rule,
+// termination / infeasibility tests and deterministic adaptive-rho schedule).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcqp.h"
+#include "plan.hpp"
+
+using namespace mpcqp;
+
+#define Q_INFTY 1e30
+#define Q_MIN_SCALING 1e-4
+#define Q_MAX_SCALING 1e4
+#define Q_RHO_MIN 1e-6
+#define Q_RHO_MAX 1e6
+#define Q_RHO_TOL 1e-4
+#define Q_RHO_EQ 1e3
+#define Q_DIV_TOL 1e-10
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct DevEll { int nchunks; const int *chunk_off, *idx, *src, *flag; long entries; };
+struct DevPlan {
+  int n, m, npad, mpad, nb, nblk, nfac, nT;
+  DevEll A, At, P;
+  const int *pos, *perm, *fwd_ops, *bwd_ops, *bwd_of;
+  const int4 *fac;
+  const int *tpos, *asm_ptr, *asm_a, *asm_b, *asm_pidx, *blk_diag;
+  long o_ellA, o_ellAt, o_ellP, o_Lf, o_Lb, o_T, o_l, o_u, o_D, o_E, o_dx, o_dy, ws_stride;
+};
+struct DevIO {
+  const double *P, *q, *A, *l, *u; long sP, sq, sA, sl, su;
+  const double *x0, *y0;
+  double *x, *y, *z; int *status, *iters; double *info;
+  double *ws; double *cscale;
+};
+
+// ------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double limit_scaling(double v) {
+  v = v < Q_MIN_SCALING ? 1.0 : v;
+  return v > Q_MAX_SCALING ? Q_MAX_SCALING : v;
+}
+__device__ __forceinline__ double rho_of(double l, double u, double rho) {
+  if (l < -Q_INFTY * Q_MIN_SCALING && u > Q_INFTY * Q_MIN_SCALING) return Q_RHO_MIN;
+  if (u - l < Q_RHO_TOL) return Q_RHO_EQ * rho;
+  return rho;
+}
+// single-wave workgroup: orders LDS / global accesses between lanes of the wave
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+// out(row, sum_s val * in[idx]) over an ELL structure; rows are lane-mapped, loads are 512 B coalesced
+template <class F>
+__device__ __forceinline__ void ell_rows(const DevEll &E, const double *__restrict__ val, const double *in, F &&f) {
+  const int lane = threadIdx.x;
+  for (int c = 0; c < E.nchunks; c++) {
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int s = s0; s < s1; s++) {
+      const long e = (long)s * WAVE + lane;
+      acc += val[e] * in[E.idx[e]];
+    }
+    f(c * WAVE + lane, acc);
+  }
+}
+// max_s |val| * in[idx]
+template <class F>
+__device__ __forceinline__ void ell_rowmax(const DevEll &E, const double *__restrict__ val, const double *in, F &&f) {
+  const int lane = threadIdx.x;
+  for (int c = 0; c < E.nchunks; c++) {
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int s = s0; s < s1; s++) {
+      const long e = (long)s * WAVE + lane;
+      acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
+    }
+    f(c * WAVE + lane, acc);
+  }
+}
+
+// acc += A * B^T for row-major 16x16 blocks in global memory, on the matrix cores.
+// v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][k0 + (l>>4)] and B^T[k][j] = B[l&15][k0 + (l>>4)];
+// result register g of lane l is C[(l>>4) + 4g][l&15].
+__device__ __forceinline__ d4 mfma_abt(const double *__restrict__ A, const double *__restrict__ B, d4 acc) {
+  const int lane = threadIdx.x, rr = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < BS; k0 += 4) {
+    const double a = A[rr * BS + k0 + kk];
+    const double b = B[rr * BS + k0 + kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// In-LDS Cholesky of a 16x16 SPD block followed by the inverse of its factor.
+// gf: block in global (in: S, lower triangle used; out: Linv, row-major, zero above the diagonal);
+// gb: transposed copy (backward stream). S0/S1: 16x17 LDS tiles. Returns false on a non-positive pivot.
+__device__ bool potrf_inv(double *gf, double *gb, double *S0, double *S1) {
+  const int lane = threadIdx.x, r = lane >> 2, j = lane & 3;
+  {
+    const d4 v = reinterpret_cast<const d4 *>(gf)[lane];
+#pragma unroll
+    for (int c = 0; c < 4; c++) S0[r * 17 + 4 * j + c] = v[c];
+  }
+  wsync();
+  for (int k = 0; k < BS; k++) {
+    const double d = S0[k * 17 + k];
+    if (!(d > 0.0)) return false;          // uniform across the wave
+    const double sd = sqrt(d), inv = 1.0 / sd;
+    const double lrk = S0[r * 17 + k] * inv;
+    double lc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) lc[c] = S0[(4 * j + c) * 17 + k] * inv;
+    wsync();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int col = 4 * j + c;
+      if (col > k && r >= col) S0[r * 17 + col] -= lrk * lc[c];
+    }
+    if ((k >> 2) == j) {
+      if (r > k) S0[r * 17 + k] = lrk;
+      else if (r == k) S0[r * 17 + k] = sd;
+    }
+    wsync();
+  }
+  if (lane < BS) {
+    const int c = lane;
+    for (int i = 0; i < BS; i++) {
+      double v;
+      if (i < c) v = 0.0;
+      else if (i == c) v = 1.0 / S0[i * 17 + i];
+      else {
+        double s = 0.0;
+        for (int k = c; k < i; k++) s += S0[i * 17 + k] * S1[k * 17 + c];
+        v = -s / S0[i * 17 + i];
+      }
+      S1[i * 17 + c] = v;
+    }
+  }
+  wsync();
+  d4 f, t;
+#pragma unroll
+  for (int c = 0; c < 4; c++) { f[c] = S1[r * 17 + 4 * j + c]; t[c] = S1[(4 * j + c) * 17 + r]; }
+  reinterpret_cast<d4 *>(gf)[lane] = f;
+  reinterpret_cast<d4 *>(gb)[lane] = t;
+  return true;
+}
+
+// Stream of 16x16 block mat-vecs over an LDS vector: op t uses block t of `blk` (2 KiB, coalesced),
+// DIAG: vec_d = B vec_s (in place), OFF: vec_d -= B vec_s. 4 lanes per row + quad shuffle reduction.
+__device__ __forceinline__ void stream_step(const d4 bb, const int op, double *vec, const int r, const int j) {
+  const int kind = op & 1, s = (op >> 1) & 0x7fff, d = op >> 16;
+  const double *v = vec + BS * s + 4 * j;
+  double part = bb[0] * v[0] + bb[1] * v[1] + bb[2] * v[2] + bb[3] * v[3];
+  part += __shfl_xor(part, 1);
+  part += __shfl_xor(part, 2);
+  if (j == 0) {
+    double *o = vec + BS * d + r;
+    *o = kind ? *o - part : part;
+  }
+  wsync();
+}
+__device__ void run_stream(const double *__restrict__ blk, const int *__restrict__ ops, const int nops, double *vec) {
+  const int lane = threadIdx.x, r = lane >> 2, j = lane & 3;
+  const d4 *p = reinterpret_cast<const d4 *>(blk) + lane;
+  d4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+  if (0 < nops) b0 = p[0];
+  if (1 < nops) b1 = p[WAVE];
+  if (2 < nops) b2 = p[2 * WAVE];
+  if (3 < nops) b3 = p[3 * WAVE];
+  for (int t = 0; t < nops; t += 4) {
+    stream_step(b0, ops[t], vec, r, j);
+    if (t + 4 < nops) b0 = p[(long)(t + 4) * WAVE];
+    if (t + 1 < nops) { stream_step(b1, ops[t + 1], vec, r, j); if (t + 5 < nops) b1 = p[(long)(t + 5) * WAVE]; }
+    if (t + 2 < nops) { stream_step(b2, ops[t + 2], vec, r, j); if (t + 6 < nops) b2 = p[(long)(t + 6) * WAVE]; }
+    if (t + 3 < nops) { stream_step(b3, ops[t + 3], vec, r, j); if (t + 7 < nops) b3 = p[(long)(t + 7) * WAVE]; }
+  }
+}
+
+// residual / norm bundle produced by update_info (oracle/osqp_oracle.c update_info + rho_estimate inputs)
+struct Info {
+  double prim_res, dual_res, obj;
+  double nz, nax, nq, naty, npx;            // norms entering eps_prim / eps_dual (unscaled unless scaled_termination)
+  double prs, drs, nzs, naxs, nqs, natys, npxs;  // scaled-space norms for the rho estimate
+};
+
+struct Ctx {
+  const DevPlan *pl; const mpcqp_settings *st; double *ws;
+  double *X, *Q, *R, *Z, *Y, *W, *S0, *S1;
+  double c, cinv, rho; int unscale;
+};
+
+// Factorise M(rho): build rho vector, singleton diagonal, T = sqrt(rho) A_general^T, assemble blocks on the
+// matrix cores, left-looking block Cholesky. Leaves W = rho*Z - Y. Returns false if M is not positive definite
+// (same inertia test as OSQP's "KKT has n positive pivots").
+__device__ bool factorize(Ctx &cx) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws;
+  const int lane = threadIdx.x;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u;
+  double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  double *Lf = ws + pl.o_Lf, *Lb = ws + pl.o_Lb, *T = ws + pl.o_T;
+  for (int i = lane; i < pl.mpad; i += WAVE) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) : 0.0;
+  wsync();
+  {
+    const double sigma = cx.st->sigma;
+    const DevEll &E = pl.At;
+    for (int c = 0; c < E.nchunks; c++) {
+      double acc = 0.0;
+      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+        const long e = (long)s * WAVE + lane;
+        const double v = valAt[e];
+        if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
+      }
+      const int t = c * WAVE + lane;
+      if (t < pl.npad) cx.R[t] = pl.perm[t] >= 0 ? sigma + acc : 1.0;
+    }
+  }
+  for (long k = lane; k < (long)pl.nT * BLK; k += WAVE) T[k] = 0.0;
+  wsync();
+  {
+    const DevEll &E = pl.A;
+    for (int c = 0; c < E.nchunks; c++) {
+      const int i = c * WAVE + lane;
+      const double sr = sqrt(cx.W[i]);
+      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+        const long e = (long)s * WAVE + lane;
+        const int tp = pl.tpos[e];
+        if (tp >= 0) T[tp] = valA[e] * sr;
+      }
+    }
+  }
+  wsync();
+  const int row0 = lane >> 4, col = lane & 15;
+  for (int b = 0; b < pl.nblk; b++) {
+    d4 acc = {0, 0, 0, 0};
+    for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) acc = mfma_abt(T + (long)pl.asm_a[g] * BLK, T + (long)pl.asm_b[g] * BLK, acc);
+    const int J = pl.blk_diag[b];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int pi = pl.asm_pidx[(long)b * BLK + g * WAVE + lane];
+      if (pi >= 0) acc[g] += valP[pi];
+      const int row = row0 + 4 * g;
+      if (J >= 0 && row == col) acc[g] += cx.R[J * BS + row];
+      Lf[(long)b * BLK + row * BS + col] = acc[g];
+    }
+  }
+  wsync();
+  for (int f = 0; f < pl.nfac; f++) {
+    const int4 op = pl.fac[f];
+    double *dst = Lf + (long)op.y * BLK;
+    if (op.x == FAC_SUB) {
+      d4 prod = {0, 0, 0, 0};
+      prod = mfma_abt(Lf + (long)op.z * BLK, Lf + (long)op.w * BLK, prod);
+#pragma unroll
+      for (int g = 0; g < 4; g++) dst[(row0 + 4 * g) * BS + col] -= prod[g];
+    } else if (op.x == FAC_POTRF) {
+      if (!potrf_inv(dst, Lb + (long)pl.bwd_of[op.y] * BLK, cx.S0, cx.S1)) return false;
+    } else {
+      d4 prod = {0, 0, 0, 0};
+      prod = mfma_abt(dst, Lf + (long)op.z * BLK, prod);
+      double *dbt = Lb + (long)pl.bwd_of[op.y] * BLK;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        dst[(row0 + 4 * g) * BS + col] = prod[g];
+        dbt[col * BS + row0 + 4 * g] = prod[g];
+      }
+    }
+    wsync();
+  }
+  for (int i = lane; i < pl.mpad; i += WAVE) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
+  wsync();
+  return true;
+}
+
+// residuals, norms and objective at the current iterate (oracle update_info); clobbers R
+__device__ void update_info(Ctx &cx, Info &in) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws;
+  const double *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
+  const double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  const int unscale = cx.unscale;
+  double pr = 0, nz = 0, nax = 0, prs = 0, nzs = 0, naxs = 0;
+  ell_rows(pl.A, valA, cx.X, [&](int i, double ax) {
+    if (i < pl.m) {
+      const double einv = unscale ? 1.0 / Eg[i] : 1.0, zi = cx.Z[i];
+      pr = fmax(pr, fabs(einv * (ax - zi))); nax = fmax(nax, fabs(einv * ax)); nz = fmax(nz, fabs(einv * zi));
+      prs = fmax(prs, fabs(ax - zi)); naxs = fmax(naxs, fabs(ax)); nzs = fmax(nzs, fabs(zi));
+    }
+  });
+  ell_rows(pl.P, valP, cx.X, [&](int t, double px) { if (t < pl.npad) cx.R[t] = px; });
+  wsync();
+  double dr = 0, nq = 0, naty = 0, npx = 0, drs = 0, nqs = 0, natys = 0, npxs = 0, obj = 0;
+  ell_rows(pl.At, valAt, cx.Y, [&](int t, double aty) {
+    if (t < pl.npad) {
+      const double dinv = unscale ? 1.0 / Dg[t] : 1.0, px = cx.R[t], qv = cx.Q[t], du = qv + px + aty;
+      dr = fmax(dr, fabs(dinv * du)); nq = fmax(nq, fabs(dinv * qv)); naty = fmax(naty, fabs(dinv * aty)); npx = fmax(npx, fabs(dinv * px));
+      drs = fmax(drs, fabs(du)); nqs = fmax(nqs, fabs(qv)); natys = fmax(natys, fabs(aty)); npxs = fmax(npxs, fabs(px));
+      obj += cx.X[t] * (0.5 * px + qv);
+    }
+  });
+  in.prim_res = wave_max(pr); in.nz = wave_max(nz); in.nax = wave_max(nax);
+  in.prs = wave_max(prs); in.nzs = wave_max(nzs); in.naxs = wave_max(naxs);
+  dr = wave_max(dr); in.nq = wave_max(nq); in.naty = wave_max(naty); in.npx = wave_max(npx);
+  in.drs = wave_max(drs); in.nqs = wave_max(nqs); in.natys = wave_max(natys); in.npxs = wave_max(npxs);
+  in.dual_res = unscale ? cx.cinv * dr : dr;
+  obj = wave_sum(obj);
+  in.obj = cx.st->scaling ? cx.cinv * obj : obj;
+  wsync();
+}
+
+// oracle is_primal_infeasible; uses W as scratch and restores W = rho*Z - Y
+__device__ bool primal_infeasible(Ctx &cx, double eps) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int lane = threadIdx.x;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dy = ws + pl.o_dy;
+  double nrm = 0, lhs = 0;
+  for (int i = lane; i < pl.mpad; i += WAVE) {
+    double v = 0.0;
+    if (i < pl.m) {
+      v = dy[i];
+      const double lo = lb[i], up = ub[i];
+      if (up > Q_INFTY * Q_MIN_SCALING) { if (lo < -Q_INFTY * Q_MIN_SCALING) v = 0.0; else v = fmin(v, 0.0); }
+      else if (lo < -Q_INFTY * Q_MIN_SCALING) v = fmax(v, 0.0);
+      nrm = fmax(nrm, fabs(cx.unscale ? Eg[i] * v : v));
+      lhs += up * fmax(v, 0.0) + lo * fmin(v, 0.0);
+    }
+    cx.W[i] = v;
+  }
+  nrm = wave_max(nrm); lhs = wave_sum(lhs);
+  wsync();
+  bool res = false;
+  if (nrm > eps && lhs < -eps * nrm) {
+    double a = 0;
+    ell_rows(pl.At, ws + pl.o_ellAt, cx.W, [&](int t, double v) { if (t < pl.npad) a = fmax(a, fabs(cx.unscale ? (1.0 / Dg[t]) * v : v)); });
+    a = wave_max(a);
+    res = a < eps * nrm;
+  }
+  wsync();
+  for (int i = lane; i < pl.mpad; i += WAVE) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
+  wsync();
+  return res;
+}
+
+// oracle is_dual_infeasible; uses R as scratch
+__device__ bool dual_infeasible(Ctx &cx, double eps) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int lane = threadIdx.x;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dx = ws + pl.o_dx;
+  double nrm = 0, qdx = 0;
+  for (int t = lane; t < pl.npad; t += WAVE) {
+    const double v = dx[t];
+    cx.R[t] = v;
+    nrm = fmax(nrm, fabs(cx.unscale ? Dg[t] * v : v));
+    qdx += cx.Q[t] * v;
+  }
+  nrm = wave_max(nrm); qdx = wave_sum(qdx);
+  wsync();
+  const double cs = cx.unscale ? cx.c : 1.0;
+  bool res = false;
+  if (nrm > eps && qdx < -cs * eps * nrm) {
+    double a = 0;
+    ell_rows(pl.P, ws + pl.o_ellP, cx.R, [&](int t, double v) { if (t < pl.npad) a = fmax(a, fabs(cx.unscale ? (1.0 / Dg[t]) * v : v)); });
+    a = wave_max(a);
+    if (a < cs * eps * nrm) {
+      int bad = 0;
+      ell_rows(pl.A, ws + pl.o_ellA, cx.R, [&](int i, double v) {
+        if (i < pl.m) {
+          if (cx.unscale) v = (1.0 / Eg[i]) * v;
+          if ((ub[i] < Q_INFTY * Q_MIN_SCALING && v > eps * nrm) || (lb[i] > -Q_INFTY * Q_MIN_SCALING && v < -eps * nrm)) bad = 1;
+        }
+      });
+      res = !__any(bad);
+    }
+  }
+  wsync();
+  return res;
+}
+
+// oracle check_termination; returns new status (or UNSOLVED)
+__device__ int check_termination(Ctx &cx, Info &in, int approximate) {
+  const mpcqp_settings &st = *cx.st;
+  double eps_abs = st.eps_abs, eps_rel = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
+  if (in.prim_res > Q_INFTY || in.dual_res > Q_INFTY || in.prim_res != in.prim_res || in.dual_res != in.dual_res) { in.obj = NAN; return MPCQP_NON_CVX; }
+  if (approximate) { eps_abs *= 10; eps_rel *= 10; epi *= 10; edi *= 10; }
+  bool pc = false, dc = false, pic = false, dic = false;
+  if (cx.pl->m == 0) pc = true;
+  else {
+    const double eps_prim = eps_abs + eps_rel * fmax(in.nz, in.nax);
+    if (in.prim_res < eps_prim) pc = true; else pic = primal_infeasible(cx, epi);
+  }
+  {
+    double mx = fmax(in.nq, fmax(in.naty, in.npx));
+    if (cx.unscale) mx *= cx.cinv;
+    const double eps_dual = eps_abs + eps_rel * mx;
+    if (in.dual_res < eps_dual) dc = true; else dic = dual_infeasible(cx, edi);
+  }
+  if (pc && dc) return approximate ? MPCQP_SOLVED_INACCURATE : MPCQP_SOLVED;
+  if (pic) { in.obj = Q_INFTY; return approximate ? MPCQP_PRIMAL_INFEASIBLE_INACCURATE : MPCQP_PRIMAL_INFEASIBLE; }
+  if (dic) { in.obj = -Q_INFTY; return approximate ? MPCQP_DUAL_INFEASIBLE_INACCURATE : MPCQP_DUAL_INFEASIBLE; }
+  return MPCQP_UNSOLVED;
+}
+
+// ------------------------------------------------------------------------------------------ the kernel
+extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, const mpcqp_settings st, const DevIO io) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  Ctx cx;
+  cx.pl = &pl; cx.st = &st;
+  cx.X = lds; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
+  cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
+  cx.S0 = cx.W + pl.mpad; cx.S1 = cx.S0 + BS * 17;
+  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
+  double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
+  const double *inP = io.P + (long)b * io.sP, *inA = io.A + (long)b * io.sA, *inq = io.q + (long)b * io.sq;
+  const double *inl = io.l + (long)b * io.sl, *inu = io.u + (long)b * io.su;
+  const int n = pl.n, m = pl.m, npad = pl.npad, mpad = pl.mpad;
+  cx.unscale = st.scaling && !st.scaled_termination;
+
+  // ---- load: caller's CSC values -> ELL slabs (CuCaQP::setSystem, reference CuCaQP.cpp:271-288)
+  for (long e = lane; e < pl.A.entries; e += WAVE) { const int s = pl.A.src[e]; valA[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = lane; e < pl.At.entries; e += WAVE) { const int s = pl.At.src[e]; valAt[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = lane; e < pl.P.entries; e += WAVE) { const int s = pl.P.src[e]; valP[e] = s >= 0 ? inP[s] : 0.0; }
+  for (int t = lane; t < npad; t += WAVE) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
+  for (int i = lane; i < mpad; i += WAVE) cx.W[i] = 1.0;
+  wsync();
+  for (int j = lane; j < n; j += WAVE) cx.Q[pl.pos[j]] = inq[j];
+  wsync();
+
+  // ---- modified Ruiz equilibration (oracle scale_data): D in R, E in W, temporaries in X / Z
+  double c = 1.0;
+  for (int it = 0; it < st.scaling; it++) {
+    {
+      const int lane_ = lane;
+      for (int ch = 0; ch < pl.At.nchunks; ch++) {
+        const int t = ch * WAVE + lane_;
+        double nA = 0.0, nP = 0.0;
+        for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane_; nA = fmax(nA, fabs(valAt[e]) * cx.W[pl.At.idx[e]]); }
+        for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane_; nP = fmax(nP, fabs(valP[e]) * cx.R[pl.P.idx[e]]); }
+        if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
+      }
+    }
+    ell_rowmax(pl.A, valA, cx.R, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+    wsync();
+    for (int t = lane; t < npad; t += WAVE) cx.R[t] *= cx.X[t];
+    for (int i = lane; i < mpad; i += WAVE) cx.W[i] *= cx.Z[i];
+    wsync();
+    double sum = 0.0, qn = 0.0;
+    ell_rowmax(pl.P, valP, cx.R, [&](int t, double v) { if (t < npad) { sum += c * cx.R[t] * v; qn = fmax(qn, fabs(c * cx.R[t] * cx.Q[t])); } });
+    sum = wave_sum(sum); qn = wave_max(qn);
+    const double ct = 1.0 / limit_scaling(fmax(sum / (double)n, limit_scaling(qn)));
+    c *= ct;
+    wsync();
+  }
+  cx.c = c; cx.cinv = 1.0 / c;
+  // apply scaling: A <- E A D, P <- c D P D, q <- c D q, l,u <- E l, E u (bounds clipped to +-1e30 first)
+  for (int ch = 0; ch < pl.A.nchunks; ch++) {
+    const int i = ch * WAVE + lane; const double ei = cx.W[i];
+    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] *= ei * cx.R[pl.A.idx[e]]; }
+  }
+  for (int ch = 0; ch < pl.At.nchunks; ch++) {
+    const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] *= dj * cx.W[pl.At.idx[e]]; }
+    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] *= c * dj * cx.R[pl.P.idx[e]]; }
+  }
+  for (int t = lane; t < npad; t += WAVE) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
+  for (int i = lane; i < mpad; i += WAVE) {
+    const double ei = cx.W[i];
+    Eg[i] = ei;
+    lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
+    ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+  }
+  wsync();
+
+  // ---- start point (cold: x = z = y = 0; warm: oracle solve_one / osqp_warm_start)
+  for (int t = lane; t < npad; t += WAVE) cx.X[t] = 0.0;
+  for (int i = lane; i < mpad; i += WAVE) { cx.Z[i] = 0.0; cx.Y[i] = 0.0; }
+  wsync();
+  if (st.warm_start && io.x0 && io.y0) {
+    for (int j = lane; j < n; j += WAVE) { const int t = pl.pos[j]; cx.X[t] = io.x0[(long)b * n + j] * (1.0 / Dg[t]); }
+    for (int i = lane; i < m; i += WAVE) cx.Y[i] = io.y0[(long)b * m + i] * (1.0 / Eg[i]) * c;
+    wsync();
+    ell_rows(pl.A, valA, cx.X, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
+    wsync();
+  }
+  cx.rho = fmin(fmax(st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  int status = MPCQP_UNSOLVED, iter_done = 0;
+  Info in; memset(&in, 0, sizeof(in));
+  bool ok = factorize(cx);
+  if (!ok) status = MPCQP_NON_CVX;
+
+  // ---- ADMM loop (OSQP Algorithm 1; oracle solve_one)
+  int interval = st.adaptive_rho_interval;
+  if (st.adaptive_rho && interval == 0) interval = st.check_termination ? 4 * st.check_termination : 100;
+  const double alpha = st.alpha, sigma = st.sigma;
+  const double *Lf = ws + pl.o_Lf, *Lbk = ws + pl.o_Lb;
+  double *dxg = ws + pl.o_dx, *dyg = ws + pl.o_dy;
+  int can_check = 0;
+  if (ok) {
+    int iter;
+    for (iter = 1; iter <= st.max_iter; iter++) {
+      // rhs = sigma x - q + A'(rho z - y)
+      ell_rows(pl.At, valAt, cx.W, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      wsync();
+      // xtilde = M^-1 rhs
+      run_stream(Lf, pl.fwd_ops, pl.nblk, cx.R);
+      run_stream(Lbk, pl.bwd_ops, pl.nblk, cx.R);
+      can_check = st.check_termination && (iter % st.check_termination == 0);
+      const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
+      const int save = can_check || do_rho;
+      // ztilde = A xtilde, fused with the z / y updates (projection onto [l, u]) and w = rho z - y
+      ell_rows(pl.A, valA, cx.R, [&](int i, double zt) {
+        if (i < m) {
+          const double lo = lb[i], up = ub[i], rh = rho_of(lo, up, cx.rho), rinv = 1.0 / rh;
+          const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
+          const double zn = fmin(fmax(zr + rinv * yo, lo), up);
+          const double dy = rh * (zr - zn), yn = yo + dy;
+          cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
+          if (save) dyg[i] = dy;
+        }
+      });
+      for (int t = lane; t < npad; t += WAVE) {
+        const double xo = cx.X[t], xn = alpha * cx.R[t] + (1.0 - alpha) * xo;
+        cx.X[t] = xn;
+        if (save) dxg[t] = xn - xo;
+      }
+      wsync();
+      iter_done = iter;
+      if (can_check) {
+        update_info(cx, in);
+        status = check_termination(cx, in, 0);
+        if (status != MPCQP_UNSOLVED) break;
+      }
+      if (do_rho) {
+        if (!can_check) update_info(cx, in);
+        const double pr = in.prs / (fmax(in.nzs, in.naxs) + Q_DIV_TOL);
+        const double dr = in.drs / (fmax(in.nqs, fmax(in.natys, in.npxs)) + Q_DIV_TOL);
+        double rn = cx.rho * sqrt(pr / (dr + Q_DIV_TOL));
+        rn = fmin(fmax(rn, Q_RHO_MIN), Q_RHO_MAX);
+        if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
+          cx.rho = rn;
+          if (!factorize(cx)) { status = MPCQP_NON_CVX; break; }
+        }
+      }
+    }
+    if (iter > st.max_iter) iter_done = st.max_iter;
+    if (status == MPCQP_UNSOLVED) {
+      if (!can_check) { update_info(cx, in); status = check_termination(cx, in, 0); }
+      if (status == MPCQP_UNSOLVED) { status = check_termination(cx, in, 1); if (status == MPCQP_UNSOLVED) status = MPCQP_MAX_ITER_REACHED; }
+    }
+  }
+
+  // ---- store_solution: x = D x, y = E y / c, z = z / E; NaN where no solution is defined
+  const bool bad = status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
+                   status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX;
+  for (int j = lane; j < n; j += WAVE) { const int t = pl.pos[j]; io.x[(long)b * n + j] = bad ? NAN : Dg[t] * cx.X[t]; }
+  for (int i = lane; i < m; i += WAVE) {
+    io.y[(long)b * m + i] = bad ? NAN : cx.cinv * Eg[i] * cx.Y[i];
+    io.z[(long)b * m + i] = bad ? NAN : (1.0 / Eg[i]) * cx.Z[i];
+  }
+  if (lane == 0) {
+    io.status[b] = status; io.iters[b] = iter_done;
+    io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
+    io.cscale[b] = c;
+  }
+}
+
+// block-primitive self test (mpcqp_debug_blockops)
+extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_blockops_kernel(const double *A, const double *B, const double *C, double *S,
+                                                                          double *out_gemm, double *Sb, int *fail) {
+  __shared__ double t0[BS * 17], t1[BS * 17];
+  const int lane = threadIdx.x, row0 = lane >> 4, col = lane & 15;
+  d4 prod = {0, 0, 0, 0};
+  prod = mfma_abt(A, B, prod);
+#pragma unroll
+  for (int g = 0; g < 4; g++) out_gemm[(row0 + 4 * g) * BS + col] = C[(row0 + 4 * g) * BS + col] - prod[g];
+  const bool ok = potrf_inv(S, Sb, t0, t1);
+  if (lane == 0) *fail = ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+#define HIPCHK(expr)                                                                              \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MPCQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct mpcqp_handle {
+  int n = 0, m = 0, batch = 0, device = 0;
+  mpcqp_settings st;
+  Plan plan; WsLayout wl; long lds = 0;
+  DevPlan dp; DevIO io;
+  std::vector<void *> dev_allocs;
+  double *ws = nullptr;
+  double *dP = nullptr, *dq = nullptr, *dA = nullptr, *dl = nullptr, *du = nullptr;  // owned copies (host-memory updates)
+  double *dx0 = nullptr, *dy0 = nullptr;
+  double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
+  bool have_data = false, solved = false;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <class T>
+static int upload(mpcqp_handle *h, const std::vector<T> &v, const T **out) {
+  void *d = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc(&d, bytes));
+  h->dev_allocs.push_back(d);
+  if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T *)d;
+  return MPCQP_OK;
+}
+static int upload_ell(mpcqp_handle *h, const Ell &e, DevEll *d) {
+  d->nchunks = e.nchunks; d->entries = e.entries();
+  int rc;
+  if ((rc = upload(h, e.chunk_off, &d->chunk_off))) return rc;
+  if ((rc = upload(h, e.idx, &d->idx))) return rc;
+  if ((rc = upload(h, e.src, &d->src))) return rc;
+  if ((rc = upload(h, e.flag, &d->flag))) return rc;
+  return MPCQP_OK;
+}
+template <class T>
+static int dalloc(mpcqp_handle *h, T **p, size_t count) {
+  void *d = nullptr;
+  HIPCHK(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)));
+  h->dev_allocs.push_back(d);
+  *p = (T *)d;
+  return MPCQP_OK;
+}
+
+extern "C" {
+
+void mpcqp_default_settings(mpcqp_settings *s) {
+  if (!s) return;
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->adaptive_rho_tolerance = 5.0;
+  s->max_iter = 10000; s->check_termination = 25; s->scaling = 10; s->adaptive_rho = 1;
+  s->adaptive_rho_interval = 0; s->scaled_termination = 0; s->warm_start = 0; s->device = -1;
+}
+
+const char *mpcqp_strerror(int code) {
+  static thread_local std::string buf;
+  const char *base = "unknown error";
+  switch (code) {
+    case MPCQP_OK: base = "ok"; break;
+    case MPCQP_ERR_ARG: base = "invalid argument"; break;
+    case MPCQP_ERR_HIP: base = "HIP runtime error"; break;
+    case MPCQP_ERR_NO_GPU: base = "no usable gfx950 GPU (this library has no CPU fallback)"; break;
+    case MPCQP_ERR_STATE: base = "call order violated"; break;
+    case MPCQP_ERR_LIMIT: base = "problem exceeds on-chip budget"; break;
+  }
+  buf = base;
+  if (code != MPCQP_OK && !g_last_error.empty()) buf += ": " + g_last_error;
+  return buf.c_str();
+}
+
+int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                 const mpcqp_settings *settings, mpcqp_handle **out) {
+  if (!out) return fail(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n <= 0 || m < 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPCQP_ERR_NO_GPU, "hipGetDeviceCount found no device");
+  mpcqp_handle *h = new mpcqp_handle();
+  if (settings) h->st = *settings; else mpcqp_default_settings(&h->st);
+  int dev = h->st.device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) { delete h; return fail(MPCQP_ERR_ARG, "device ordinal out of range"); }
+  h->device = dev;
+  auto bail = [&](int rc) { mpcqp_destroy(h); return rc; };
+  if (hipSetDevice(dev) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipSetDevice failed"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipGetDeviceProperties failed"));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return bail(fail(MPCQP_ERR_NO_GPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"));
+  h->n = n; h->m = m; h->batch = batch;
+  h->plan = build_plan(n, m, Pp, Pi, Ap, Ai);
+  if (!h->plan.error.empty()) return bail(fail(MPCQP_ERR_ARG, h->plan.error));
+  const Plan &pl = h->plan;
+  h->wl = ws_layout(pl);
+  h->lds = lds_bytes(pl);
+  if (h->lds > 160 * 1024) return bail(fail(MPCQP_ERR_LIMIT, "LDS footprint " + std::to_string(h->lds) + " B exceeds 160 KiB per CU"));
+  DevPlan &dp = h->dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.n = n; dp.m = m; dp.npad = pl.npad; dp.mpad = pl.mpad; dp.nb = pl.nb; dp.nblk = pl.nblk; dp.nfac = (int)pl.fac.size(); dp.nT = pl.nT;
+  int rc;
+#define UP(expr) if ((rc = (expr))) return bail(rc)
+  UP(upload_ell(h, pl.A, &dp.A)); UP(upload_ell(h, pl.At, &dp.At)); UP(upload_ell(h, pl.P, &dp.P));
+  UP(upload(h, pl.pos, &dp.pos)); UP(upload(h, pl.perm, &dp.perm));
+  UP(upload(h, pl.fwd_ops, &dp.fwd_ops)); UP(upload(h, pl.bwd_ops, &dp.bwd_ops)); UP(upload(h, pl.bwd_of, &dp.bwd_of));
+  {
+    std::vector<int4> f(pl.fac.size());
+    for (size_t i = 0; i < f.size(); i++) f[i] = make_int4(pl.fac[i].type, pl.fac[i].dst, pl.fac[i].a, pl.fac[i].b);
+    UP(upload(h, f, &dp.fac));
+  }
+  UP(upload(h, pl.tpos, &dp.tpos)); UP(upload(h, pl.asm_ptr, &dp.asm_ptr)); UP(upload(h, pl.asm_a, &dp.asm_a));
+  UP(upload(h, pl.asm_b, &dp.asm_b)); UP(upload(h, pl.asm_pidx, &dp.asm_pidx)); UP(upload(h, pl.blk_diag, &dp.blk_diag));
+  const WsLayout &w = h->wl;
+  dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
+  dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.ws_stride = w.stride;
+  UP(dalloc(h, &h->ws, (size_t)w.stride * batch));
+  UP(dalloc(h, &h->ox, (size_t)batch * n)); UP(dalloc(h, &h->oy, (size_t)batch * std::max(m, 1))); UP(dalloc(h, &h->oz, (size_t)batch * std::max(m, 1)));
+  UP(dalloc(h, &h->oinfo, (size_t)batch * 4)); UP(dalloc(h, &h->ocs, (size_t)batch));
+  UP(dalloc(h, &h->ostatus, (size_t)batch)); UP(dalloc(h, &h->oiters, (size_t)batch));
+#undef UP
+  if (h->lds > 48 * 1024) {
+    if (hipFuncSetAttribute((const void *)mpcqp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
+      return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
+  }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
+  memset(&h->io, 0, sizeof(h->io));
+  *out = h;
+  return MPCQP_OK;
+}
+
+static int stage(mpcqp_handle *h, double **own, const double *src, long stride, long width, const double **dst, long *dstride) {
+  // host-memory update: copy into an owned device buffer
+  size_t count = stride == 0 ? (size_t)width : (size_t)stride * (h->batch - 1) + width;
+  if (!*own) { int rc = dalloc(h, own, (size_t)std::max<long>(width, 1) * h->batch); if (rc) return rc; }
+  if (stride != 0 && stride != width) {
+    for (int b = 0; b < h->batch; b++) HIPCHK(hipMemcpy(*own + (size_t)b * width, src + (size_t)b * stride, width * sizeof(double), hipMemcpyHostToDevice));
+    *dstride = width;
+  } else {
+    HIPCHK(hipMemcpy(*own, src, count * sizeof(double), hipMemcpyHostToDevice));
+    *dstride = stride;
+  }
+  *dst = *own;
+  return MPCQP_OK;
+}
+
+int mpcqp_update(mpcqp_handle *h, const double *P, long sP, const double *q, long sq, const double *A, long sA,
+                 const double *l, long sl, const double *u, long su, int mem) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!q || (h->plan.nnzP_in > 0 && !P) || (h->plan.nnzA_in > 0 && !A) || (h->m > 0 && (!l || !u))) return fail(MPCQP_ERR_ARG, "null data pointer");
+  if (sP < 0 || sq < 0 || sA < 0 || sl < 0 || su < 0) return fail(MPCQP_ERR_ARG, "negative stride");
+  if ((sP && sP < h->plan.nnzP_in) || (sq && sq < h->n) || (sA && sA < h->plan.nnzA_in) || (sl && sl < h->m) || (su && su < h->m))
+    return fail(MPCQP_ERR_ARG, "stride smaller than the array it strides (dimension mismatch)");
+  HIPCHK(hipSetDevice(h->device));
+  DevIO &io = h->io;
+  if (mem == MPCQP_MEM_DEVICE) {
+    io.P = P; io.sP = sP; io.q = q; io.sq = sq; io.A = A; io.sA = sA; io.l = l; io.sl = sl; io.u = u; io.su = su;
+  } else if (mem == MPCQP_MEM_HOST) {
+    if (h->last_stream || h->solved) HIPCHK(hipStreamSynchronize(h->last_stream));
+    int rc;
+    if ((rc = stage(h, &h->dP, P ? P : q, sP, h->plan.nnzP_in, &io.P, &io.sP))) return rc;
+    if ((rc = stage(h, &h->dq, q, sq, h->n, &io.q, &io.sq))) return rc;
+    if ((rc = stage(h, &h->dA, A ? A : q, sA, h->plan.nnzA_in, &io.A, &io.sA))) return rc;
+    if ((rc = stage(h, &h->dl, l ? l : q, sl, h->m, &io.l, &io.sl))) return rc;
+    if ((rc = stage(h, &h->du, u ? u : q, su, h->m, &io.u, &io.su))) return rc;
+  } else return fail(MPCQP_ERR_ARG, "mem must be MPCQP_MEM_HOST or MPCQP_MEM_DEVICE");
+  h->have_data = true;
+  return MPCQP_OK;
+}
+
+int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int mem) {
+  if (!h || !x0 || !y0) return fail(MPCQP_ERR_ARG, "null pointer");
+  HIPCHK(hipSetDevice(h->device));
+  if (mem == MPCQP_MEM_DEVICE) { h->io.x0 = x0; h->io.y0 = y0; return MPCQP_OK; }
+  int rc;
+  if (!h->dx0) { if ((rc = dalloc(h, &h->dx0, (size_t)h->batch * h->n))) return rc; if ((rc = dalloc(h, &h->dy0, (size_t)h->batch * std::max(h->m, 1)))) return rc; }
+  HIPCHK(hipMemcpy(h->dx0, x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->dy0, y0, (size_t)h->batch * h->m * sizeof(double), hipMemcpyHostToDevice));
+  h->io.x0 = h->dx0; h->io.y0 = h->dy0;
+  return MPCQP_OK;
+}
+
+int mpcqp_solve(mpcqp_handle *h, void *stream) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!h->have_data) return fail(MPCQP_ERR_STATE, "Solver not initialized. Call mpcqp_update() first.");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  DevIO io = h->io;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs;
+  HIPCHK(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(mpcqp_admm_kernel, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, s));
+  h->last_stream = s; h->solved = true;
+  return MPCQP_OK;
+}
+
+int mpcqp_get(mpcqp_handle *h, double *x, double *y, double *z, int *status, int *iters, double *info, int mem) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
+  HIPCHK(hipSetDevice(h->device));
+  hipMemcpyKind k = mem == MPCQP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  hipStream_t s = h->last_stream;
+  const size_t B = h->batch;
+  if (x) HIPCHK(hipMemcpyAsync(x, h->ox, B * h->n * sizeof(double), k, s));
+  if (y && h->m) HIPCHK(hipMemcpyAsync(y, h->oy, B * h->m * sizeof(double), k, s));
+  if (z && h->m) HIPCHK(hipMemcpyAsync(z, h->oz, B * h->m * sizeof(double), k, s));
+  if (status) HIPCHK(hipMemcpyAsync(status, h->ostatus, B * sizeof(int), k, s));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, h->oiters, B * sizeof(int), k, s));
+  if (info) HIPCHK(hipMemcpyAsync(info, h->oinfo, B * 4 * sizeof(double), k, s));
+  if (mem != MPCQP_MEM_DEVICE) HIPCHK(hipStreamSynchronize(s));
+  return MPCQP_OK;
+}
+
+int mpcqp_sync(mpcqp_handle *h) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->last_stream));
+  return MPCQP_OK;
+}
+
+void mpcqp_destroy(mpcqp_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->solved) (void)hipStreamSynchronize(h->last_stream);
+  for (void *p : h->dev_allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms) {
+  if (!h || !ms) return fail(MPCQP_ERR_ARG, "null pointer");
+  if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return MPCQP_OK;
+}
+
+int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
+  if (!h || !o) return fail(MPCQP_ERR_ARG, "null pointer");
+  const Plan &pl = h->plan;
+  o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
+  o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
+  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = 0;
+  return MPCQP_OK;
+}
+
+int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c) {
+  if (!h || b < 0 || b >= h->batch) return fail(MPCQP_ERR_ARG, "bad instance index");
+  if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->last_stream));
+  const Plan &pl = h->plan;
+  std::vector<double> Dp(pl.npad);
+  const double *base = h->ws + (size_t)b * h->wl.stride;
+  if (D) { HIPCHK(hipMemcpy(Dp.data(), base + h->wl.D, pl.npad * sizeof(double), hipMemcpyDeviceToHost)); for (int j = 0; j < h->n; j++) D[j] = Dp[pl.pos[j]]; }
+  if (E && h->m) HIPCHK(hipMemcpy(E, base + h->wl.E, h->m * sizeof(double), hipMemcpyDeviceToHost));
+  if (c) HIPCHK(hipMemcpy(c, h->ocs + b, sizeof(double), hipMemcpyDeviceToHost));
+  return MPCQP_OK;
+}
+
+int mpcqp_debug_blockops(const double *A, const double *B, const double *C, const double *S, double *out_gemm, double *out_linv, int *potrf_fail) {
+  if (!A || !B || !C || !S || !out_gemm || !out_linv || !potrf_fail) return fail(MPCQP_ERR_ARG, "null pointer");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPCQP_ERR_NO_GPU, "no device");
+  double *d = nullptr; int *df = nullptr;
+  HIPCHK(hipMalloc((void **)&d, 6 * BLK * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&df, sizeof(int)));
+  HIPCHK(hipMemcpy(d, A, BLK * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d + BLK, B, BLK * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + 2 * BLK, C, BLK * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d + 3 * BLK, S, BLK * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mpcqp_blockops_kernel, dim3(1), dim3(WAVE), 0, 0, d, d + BLK, d + 2 * BLK, d + 3 * BLK, d + 4 * BLK, d + 5 * BLK, df);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_gemm, d + 4 * BLK, BLK * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out_linv, d + 3 * BLK, BLK * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(potrf_fail, df, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d); (void)hipFree(df);
+  return MPCQP_OK;
+}
+
+}  // extern "C"

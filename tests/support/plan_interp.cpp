@@ -1,0 +1,140 @@
+// plan_interp.cpp -- TEST INFRASTRUCTURE ONLY (built by __graft_entry__.build(), loaded by tests/test_plan.py).
+//
+// Scalar CPU interpreter of the host-side plan (optimal_control_problem_amd/csrc/plan.hpp): executes the
+// ELL layouts, the assembly recipe, the block-Cholesky op list and the forward/backward block streams
+// exactly as the HIP kernel is meant to, so that indexing mistakes in the plan show up in the CPU test
+// suite. It is never linked into libmpcqp.so and is not a fallback for it.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../optimal_control_problem_amd/csrc/plan.hpp"
+
+using namespace mpcqp;
+
+static void gemm_abt(const double *A, const double *B, double *C, double sign) {  // C += sign * A B'
+  for (int i = 0; i < BS; i++) for (int j = 0; j < BS; j++) {
+    double s = 0;
+    for (int k = 0; k < BS; k++) s += A[i * BS + k] * B[j * BS + k];
+    C[i * BS + j] += sign * s;
+  }
+}
+
+static bool potrf_inv(double *S, double *ST) {
+  double L[BLK] = {0}, X[BLK] = {0};
+  for (int j = 0; j < BS; j++) {
+    double d = S[j * BS + j];
+    for (int k = 0; k < j; k++) d -= L[j * BS + k] * L[j * BS + k];
+    if (!(d > 0)) return false;
+    d = std::sqrt(d); L[j * BS + j] = d;
+    for (int i = j + 1; i < BS; i++) {
+      double s = S[i * BS + j];
+      for (int k = 0; k < j; k++) s -= L[i * BS + k] * L[j * BS + k];
+      L[i * BS + j] = s / d;
+    }
+  }
+  for (int c = 0; c < BS; c++) for (int i = c; i < BS; i++) {
+    if (i == c) X[i * BS + c] = 1.0 / L[i * BS + i];
+    else { double s = 0; for (int k = c; k < i; k++) s += L[i * BS + k] * X[k * BS + c]; X[i * BS + c] = -s / L[i * BS + i]; }
+  }
+  for (int i = 0; i < BS; i++) for (int j = 0; j < BS; j++) { S[i * BS + j] = X[i * BS + j]; ST[j * BS + i] = X[i * BS + j]; }
+  return true;
+}
+
+static void run_stream(const std::vector<double> &blk, const std::vector<int> &ops, std::vector<double> &vec) {
+  for (size_t t = 0; t < ops.size(); t++) {
+    int op = ops[t], kind = op & 1, s = (op >> 1) & 0x7fff, d = op >> 16;
+    double out[BS];
+    for (int r = 0; r < BS; r++) { double a = 0; for (int c = 0; c < BS; c++) a += blk[t * BLK + r * BS + c] * vec[s * BS + c]; out[r] = a; }
+    for (int r = 0; r < BS; r++) vec[d * BS + r] = kind ? vec[d * BS + r] - out[r] : out[r];
+  }
+}
+
+static void ell_fill(const Ell &e, const double *in, std::vector<double> &val) {
+  val.assign(e.entries(), 0.0);
+  for (long p = 0; p < e.entries(); p++) if (e.src[p] >= 0) val[p] = in[e.src[p]];
+}
+static void ell_spmv(const Ell &e, const std::vector<double> &val, const std::vector<double> &in, std::vector<double> &out) {
+  out.assign((size_t)e.nchunks * WAVE, 0.0);
+  for (int c = 0; c < e.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    double a = 0;
+    for (int s = e.chunk_off[c]; s < e.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; a += val[p] * in[e.idx[p]]; }
+    out[c * WAVE + lane] = a;
+  }
+}
+
+extern "C" {
+
+// info[0..7] = npad, mpad, nb, nblk, nT, n_fac, ordering, lds_bytes
+int plan_describe(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering, long *info, int *pos_out) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force_ordering);
+  if (!pl.error.empty()) return 1;
+  info[0] = pl.npad; info[1] = pl.mpad; info[2] = pl.nb; info[3] = pl.nblk; info[4] = pl.nT; info[5] = (long)pl.fac.size();
+  info[6] = pl.ordering; info[7] = lds_bytes(pl);
+  if (pos_out) for (int j = 0; j < n; j++) pos_out[j] = pl.pos[j];
+  return 0;
+}
+
+// Executes the plan for one QP's matrices: x = (P + sigma I + A' diag(rho) A)^-1 rhs, plus the three ELL
+// products Ax = A*xin, Atw = A'*win, Px = P*xin (xin/Atw/Px in original variable order).
+// returns 0 ok, 1 plan error, 2 not positive definite
+int plan_execute(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering,
+                 const double *Pval, const double *Aval, const double *rho, double sigma,
+                 const double *rhs, double *sol, const double *xin, const double *win, double *Ax, double *Atw, double *Px) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force_ordering);
+  if (!pl.error.empty()) return 1;
+  std::vector<double> vA, vAt, vP;
+  ell_fill(pl.A, Aval, vA); ell_fill(pl.At, Aval, vAt); ell_fill(pl.P, Pval, vP);
+  // ELL products
+  std::vector<double> xp(pl.npad, 0.0), wp(pl.mpad, 0.0), o;
+  for (int j = 0; j < n; j++) xp[pl.pos[j]] = xin[j];
+  for (int i = 0; i < m; i++) wp[i] = win[i];
+  ell_spmv(pl.A, vA, xp, o); for (int i = 0; i < m; i++) Ax[i] = o[i];
+  ell_spmv(pl.At, vAt, wp, o); for (int j = 0; j < n; j++) Atw[j] = o[pl.pos[j]];
+  ell_spmv(pl.P, vP, xp, o); for (int j = 0; j < n; j++) Px[j] = o[pl.pos[j]];
+  // dvec
+  std::vector<double> dvec(pl.npad, 1.0);
+  for (int c = 0; c < pl.At.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int t = c * WAVE + lane; if (t >= pl.npad) continue;
+    double a = 0;
+    for (int s = pl.At.chunk_off[c]; s < pl.At.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.At.flag[p]) a += rho[pl.At.idx[p]] * vAt[p] * vAt[p]; }
+    dvec[t] = pl.perm[t] >= 0 ? sigma + a : 1.0;
+  }
+  // T
+  std::vector<double> T((size_t)std::max(pl.nT, 1) * BLK, 0.0);
+  for (int c = 0; c < pl.A.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int i = c * WAVE + lane; if (i >= m) continue;
+    for (int s = pl.A.chunk_off[c]; s < pl.A.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.tpos[p] >= 0) T[pl.tpos[p]] = vA[p] * std::sqrt(rho[i]); }
+  }
+  // assemble in the MFMA C layout order
+  std::vector<double> Lf((size_t)pl.nblk * BLK, 0.0), Lb((size_t)pl.nblk * BLK, 0.0);
+  for (int b = 0; b < pl.nblk; b++) {
+    double *C = &Lf[(size_t)b * BLK];
+    for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) gemm_abt(&T[(size_t)pl.asm_a[g] * BLK], &T[(size_t)pl.asm_b[g] * BLK], C, 1.0);
+    for (int g = 0; g < 4; g++) for (int lane = 0; lane < WAVE; lane++) {
+      int row = (lane >> 4) + 4 * g, col = lane & 15;
+      int pi = pl.asm_pidx[(size_t)b * BLK + g * WAVE + lane];
+      if (pi >= 0) C[row * BS + col] += vP[pi];
+      if (pl.blk_diag[b] >= 0 && row == col) C[row * BS + col] += dvec[pl.blk_diag[b] * BS + row];
+    }
+  }
+  for (auto &op : pl.fac) {
+    double *dst = &Lf[(size_t)op.dst * BLK];
+    if (op.type == FAC_SUB) gemm_abt(&Lf[(size_t)op.a * BLK], &Lf[(size_t)op.b * BLK], dst, -1.0);
+    else if (op.type == FAC_POTRF) { if (!potrf_inv(dst, &Lb[(size_t)pl.bwd_of[op.dst] * BLK])) return 2; }
+    else {
+      double tmp[BLK] = {0};
+      gemm_abt(dst, &Lf[(size_t)op.a * BLK], tmp, 1.0);
+      double *bt = &Lb[(size_t)pl.bwd_of[op.dst] * BLK];
+      for (int i = 0; i < BS; i++) for (int j = 0; j < BS; j++) { dst[i * BS + j] = tmp[i * BS + j]; bt[j * BS + i] = tmp[i * BS + j]; }
+    }
+  }
+  std::vector<double> v(pl.npad, 0.0);
+  for (int j = 0; j < n; j++) v[pl.pos[j]] = rhs[j];
+  run_stream(Lf, pl.fwd_ops, v);
+  run_stream(Lb, pl.bwd_ops, v);
+  for (int j = 0; j < n; j++) sol[j] = v[pl.pos[j]];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+"""Shared problem builders for the test-suite (test infrastructure)."""
+import numpy as np
+
+from optimal_control_problem_amd import models
+
+
+def toy_local_system(mdl, arg, x=None):
+    p = np.asarray(arg["p"], float).reshape(1, -1)
+    x = np.zeros((1, mdl.nx)) if x is None else np.asarray(x, float).reshape(1, -1)
+    return mdl.local_system(p, x, np.asarray(arg["lbx"], float)[None], np.asarray(arg["ubx"], float)[None],
+                            np.asarray(arg["lbg"], float).reshape(1, -1), np.asarray(arg["ubg"], float).reshape(1, -1))
+
+
+def oracle_solve(ls, settings=None, nthreads=1, **kw):
+    from oracle import oracle as orc
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    s = settings or orc.default_settings(**kw)
+    return pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, s, nthreads=nthreads)
+
+
+def random_qp(n, m, seed, density=0.3, infeasible=None):
+    """Random strictly convex QP with mixed equality / inequality / one-sided / free rows, dense patterns."""
+    rng = np.random.default_rng(seed)
+    Mx = rng.normal(size=(n, n)) * (rng.random((n, n)) < density)
+    P = Mx @ Mx.T + 0.1 * np.eye(n)
+    A = rng.normal(size=(m, n)) * (rng.random((m, n)) < density)
+    for i in range(m):
+        if not A[i].any():
+            A[i, rng.integers(n)] = 1.0
+    xf = rng.normal(size=n)
+    ax = A @ xf
+    l = ax - rng.random(m); u = ax + rng.random(m)
+    kind = rng.integers(0, 4, size=m)
+    l[kind == 1] = -np.inf; u[kind == 2] = np.inf
+    eq = kind == 3
+    u[eq] = l[eq] = ax[eq]
+    q = rng.normal(size=n)
+    if infeasible == "primal":      # two contradictory rows
+        A[0] = 0; A[0, 0] = 1.0; A[1] = 0; A[1, 0] = 1.0
+        l[0], u[0] = 1.0, 2.0; l[1], u[1] = -2.0, -1.0
+    if infeasible == "dual":        # unbounded direction: zero curvature + free along e0
+        P[0, :] = 0; P[:, 0] = 0; A[:, 0] = 0; q[0] = -1.0
+    hm = np.ones((n, n), bool); am = np.ones((m, n), bool)
+    Pp, Pi = models._csc_from_dense_mask(hm); Ap, Ai = models._csc_from_dense_mask(am)
+    return models.LocalSystem(n, m, Pp, Pi, Ap, Ai, P.T[hm.T][None].copy(), q[None].copy(), A.T[am.T][None].copy(), l[None].copy(), u[None].copy())
