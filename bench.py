@@ -27,6 +27,28 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_M
 FP64_VEC_PEAK_TFLOPS = 78.6
 
 
+def host_cores():
+    """CPU threads this process may actually use: min(logical CPUs, affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0]); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def algorithmic_bytes_per_solve(nnzP_triu, nnzA, n, m, warm=False):
     """compulsory traffic with the iteration resident on-chip."""
     b = 8 * (nnzP_triu + nnzA + n + 2 * m) + 8 * (n + m) + 16
@@ -132,19 +154,22 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # the oracle (CPU port of the same algorithm) on this box's host cores, bounded sample of the same workload
             from oracle import oracle as orc
-            cores = os.cpu_count() or 1
+            cores = int(os.environ.get("MPCQP_CPU_THREADS", "0")) or host_cores()
             ns = min(batch, args.cpu_sample or {"quadrotor": 8192, "double_integrator": 4096, "cartpole": 2048}[args.workload])
             pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
             st = orc.default_settings()
             pat.solve(ls.P[:64], ls.q[:64], ls.A[:64], ls.l[:64], ls.u[:64], st, nthreads=cores)  # warm the threads
-            t1 = time.perf_counter()
-            ref = pat.solve(ls.P[:ns], ls.q[:ns], ls.A[:ns], ls.l[:ns], ls.u[:ns], st, nthreads=cores)
-            tc = time.perf_counter() - t1
+            reps = 0; tc = 0.0
+            while tc * cores < 12.0 and reps < 50:       # ~10-30 s of CPU work in total
+                t1 = time.perf_counter()
+                ref = pat.solve(ls.P[:ns], ls.q[:ns], ls.A[:ns], ls.l[:ns], ls.u[:ns], st, nthreads=cores)
+                tc += time.perf_counter() - t1; reps += 1
+            tc /= reps
             xg = ox[:ns].cpu().numpy()
             fin = np.isfinite(ref["x"])
             out["cpu_baseline"] = {"value": ns / tc, "unit": "QP solves/s", "cores": cores, "kind": "port",
                                    "sample": "first %d QPs of the same batch, OpenMP over instances, sparse LDL' per QP "
-                                             "(symbolic analysis shared), %.2f s wall" % (ns, tc)}
+                                             "(symbolic analysis shared), %d repetitions, %.2f s wall each, logical CPUs on the box %d" % (ns, reps, tc, os.cpu_count() or 0)}
             out["parity"] = {"max_abs_x_err_vs_oracle": float(np.abs(xg[fin] - ref["x"][fin]).max()),
                              "iters_equal": bool((iters[:ns] == ref["iters"]).all()),
                              "status_equal": bool((status[:ns] == ref["status"]).all())}

@@ -1,0 +1,21 @@
+"""optimal_control_problem_amd -- MI355X-native batched QP engine for the SQP-MPC hot path of
+LockedFlysher/optimal_control_problem (src/sqp_solver), behind the C ABI of include/mpcqp.h.
+
+Importing the package never touches the GPU; the first compute call loads libmpcqp.so and fails loudly if
+the library or a gfx950 device is missing (there is no CPU fallback)."""
+from . import models  # noqa: F401
+
+__all__ = ["models", "BatchQP", "CuCaQP", "SQPOptimizationSolver"]
+
+
+def __getattr__(name):
+    if name == "BatchQP":
+        from .batch_qp import BatchQP
+        return BatchQP
+    if name == "CuCaQP":
+        from .cucaqp import CuCaQP
+        return CuCaQP
+    if name == "SQPOptimizationSolver":
+        from .sqp import SQPOptimizationSolver
+        return SQPOptimizationSolver
+    raise AttributeError(name)

@@ -1,0 +1,219 @@
+"""CuCaQP -- host-side mirror of the reference's QP adapter class, batched.
+
+Same member names, call order, argument meaning and error behaviour as the reference class
+(reference include/optimal_control_problem/sqp_solver/CuCaQP.h:27-102, src/sqp_solver/CuCaQP.cpp): setters return
+bool and print "Error: ..." to stderr instead of raising; setSystem takes [P, q, A, l, u] in that order
+(CuCaQP.cpp:283-287) and clears the previous solver state (CuCaQP.cpp:271-280); initSolver + solve run the QP.
+Differences, all additive: one object holds a batch of QPs of one sparsity (leading axis of the value
+arrays; the reference's batch is 1), values stay fp64 (the reference's OSQP build is float,
+cpu_install.sh:44), and duals/status/iterations are retrievable.
+
+A sparse matrix is passed as a CSC triple (colptr, rowidx, values); values is [nnz] or [batch, nnz].
+"""
+import sys
+
+import numpy as np
+
+from . import _lib
+from .batch_qp import BatchQP
+
+
+def _err(msg):
+    print("Error: " + msg, file=sys.stderr)
+    return False
+
+
+class CuCaQP:
+    def __init__(self, batch=1, device=-1):
+        self.batch = int(batch)
+        self._device = device
+        self.numOfVariables_ = 0
+        self.numOfConstraints_ = 0
+        self.isInitialized_ = False
+        self._kw = {}
+        self._P = self._A = None            # (colptr, rowidx, values)
+        self.gradient = self.lowerBound = self.upperBound = None
+        self._qp = None
+        self._pattern_key = None
+        self._result = None
+
+    # -- dimensions (CuCaQP.cpp:23-41)
+    def setDimension(self, numOfVariables, numOfConstraints):
+        if numOfVariables <= 0 or numOfConstraints <= 0:
+            return _err("Invalid dimensions.")
+        self._clear_solver()
+        self.numOfVariables_ = int(numOfVariables)
+        self.numOfConstraints_ = int(numOfConstraints)
+        return True
+
+    # -- settings pass-through (CuCaQP.cpp:163-181)
+    def setVerbosity(self, verbosity):
+        self._kw["verbose"] = bool(verbosity)
+
+    def setWarmStart(self, warmStart):
+        # kept for API parity; like the reference the flag is moot because setSystem clears the solver
+        self._kw["warm_start_flag"] = bool(warmStart)
+
+    def setAbsoluteTolerance(self, tolerance):
+        self._kw["eps_abs"] = float(tolerance)
+
+    def setRelativeTolerance(self, tolerance):
+        self._kw["eps_rel"] = float(tolerance)
+
+    def setMaxIteration(self, maxIteration):
+        self._kw["max_iter"] = int(maxIteration)
+
+    def setSolverSetting(self, **kw):
+        """extension: any field of mpcqp_settings (rho, sigma, alpha, scaling, adaptive_rho, ...)"""
+        self._kw.update(kw)
+
+    # -- data (CuCaQP.cpp:43-103)
+    def _vec(self, v, size, what):
+        v = np.asarray(v, dtype=np.float64)
+        if v.ndim == 1:
+            v = np.broadcast_to(v, (self.batch, v.shape[0]))
+        if v.shape != (self.batch, size):
+            _err("%s vector size mismatch. Expected %d" % (what, size))
+            return None
+        return np.ascontiguousarray(v)
+
+    def _mat(self, csc, rows, cols, what):
+        if hasattr(csc, "tocsc"):          # scipy.sparse
+            c = csc.tocsc(); c.sort_indices()
+            if c.shape != (rows, cols):
+                _err("%s matrix dimensions mismatch. Expected %dx%d" % (what, rows, cols))
+                return None
+            return (np.asarray(c.indptr, np.int32), np.asarray(c.indices, np.int32), np.asarray(c.data, np.float64))
+        colptr, rowidx, values = csc
+        colptr = np.asarray(colptr, np.int32); rowidx = np.asarray(rowidx, np.int32); values = np.asarray(values, np.float64)
+        if len(colptr) != cols + 1 or (len(rowidx) and (rowidx.min() < 0 or rowidx.max() >= rows)) or values.shape[-1] != len(rowidx):
+            _err("%s matrix dimensions mismatch. Expected %dx%d" % (what, rows, cols))
+            return None
+        return (colptr, rowidx, values)
+
+    def setHessianMatrix(self, hessian):
+        m = self._mat(hessian, self.numOfVariables_, self.numOfVariables_, "Hessian")
+        if m is None:
+            return False
+        self._P = m
+        return True
+
+    def setGradient(self, q):
+        v = self._vec(q, self.numOfVariables_, "Gradient")
+        if v is None:
+            return False
+        self.gradient = v
+        return True
+
+    def setLinearConstraintsMatrix(self, A):
+        m = self._mat(A, self.numOfConstraints_, self.numOfVariables_, "Constraint")
+        if m is None:
+            return False
+        self._A = m
+        return True
+
+    def setLowerBound(self, l):
+        v = self._vec(l, self.numOfConstraints_, "Lower bound")
+        if v is None:
+            return False
+        self.lowerBound = v
+        return True
+
+    def setUpperBound(self, u):
+        v = self._vec(u, self.numOfConstraints_, "Upper bound")
+        if v is None:
+            return False
+        self.upperBound = v
+        return True
+
+    def setSystem(self, localSystem):
+        """[P, q, A, l, u] (CuCaQP.cpp:271-288) or a models.LocalSystem; return values are dropped like the reference"""
+        self.isInitialized_ = False
+        self._result = None
+        if hasattr(localSystem, "Pp"):
+            ls = localSystem
+            localSystem = [(ls.Pp, ls.Pi, ls.P), ls.q, (ls.Ap, ls.Ai, ls.A), ls.l, ls.u]
+        self.setHessianMatrix(localSystem[0])
+        self.setGradient(localSystem[1])
+        self.setLinearConstraintsMatrix(localSystem[2])
+        self.setLowerBound(localSystem[3])
+        self.setUpperBound(localSystem[4])
+
+    # -- solve (CuCaQP.cpp:183-211)
+    def _clear_solver(self):
+        self.isInitialized_ = False
+        self._result = None
+
+    def initSolver(self):
+        self._clear_solver()
+        if self._P is None or self._A is None or self.gradient is None or self.lowerBound is None or self.upperBound is None:
+            return _err("Failed to initialize solver.")
+        key = (self.numOfVariables_, self.numOfConstraints_, self.batch, self._P[0].tobytes(), self._P[1].tobytes(),
+               self._A[0].tobytes(), self._A[1].tobytes(), tuple(sorted((k, v) for k, v in self._kw.items())))
+        try:
+            if self._qp is None or key != self._pattern_key:
+                if self._qp is not None:
+                    self._qp.close()
+                kw = {k: v for k, v in self._kw.items() if k not in ("verbose", "warm_start_flag")}
+                self._qp = BatchQP(self.numOfVariables_, self.numOfConstraints_, self.batch, self._P[0], self._P[1],
+                                   self._A[0], self._A[1], device=self._device, **kw)
+                self._pattern_key = key
+            self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
+        except (_lib.MpcqpError, ValueError) as e:
+            return _err("Failed to initialize solver. (%s)" % e)
+        self.isInitialized_ = True
+        return True
+
+    def solve(self):
+        if not self.isInitialized_:
+            return _err("Solver not initialized. Call initSolver() first.")
+        try:
+            self._qp.solve()
+            self._result = self._qp.get()
+        except _lib.MpcqpError as e:
+            return _err("Failed to solve problem. Error code: %d" % e.code)
+        if self._kw.get("verbose"):
+            r = self._result
+            print("mpcqp: status %s iters %s" % (sorted(set(r["status"].tolist())), sorted(set(r["iters"].tolist()))))
+        return True
+
+    # -- results (CuCaQP.cpp:213-224)
+    def getSolution(self):
+        if self._result is None:
+            return np.zeros((self.batch, self.numOfVariables_))
+        return self._result["x"]
+
+    def getSolutionAsDM(self):
+        return self.getSolution()
+
+    def getDual(self):
+        return None if self._result is None else self._result["y"]
+
+    def getStatus(self):
+        return None if self._result is None else self._result["status"]
+
+    def getIterations(self):
+        return None if self._result is None else self._result["iters"]
+
+    def getInfo(self):
+        return self._result
+
+    def printSolverData(self):
+        """CuCaQP.cpp:226-269: dumps q, l, u, P, A of instance 0 as the solver holds them (plus the scaling)."""
+        print("q:", self.gradient[0]); print("l:", self.lowerBound[0]); print("u:", self.upperBound[0])
+        for name, mat in (("P", self._P), ("A", self._A)):
+            colptr, rowidx, values = mat
+            vals = values if values.ndim == 1 else values[0]
+            print("%s (nonzeros):" % name)
+            for j in range(len(colptr) - 1):
+                for k in range(colptr[j], colptr[j + 1]):
+                    print("(%d,%d): %g" % (rowidx[k], j, vals[k]))
+        if self._qp is not None and self._result is not None:
+            D, E, c = self._qp.debug_scaling(0)
+            print("scaling c:", c, "D:", D, "E:", E)
+
+    def close(self):
+        if self._qp is not None:
+            self._qp.close()
+            self._qp = None
+

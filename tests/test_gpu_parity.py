@@ -159,3 +159,118 @@ def test_error_behaviour(built):
     with pytest.raises(ValueError):
         qp.update(ls.P[:, :-1], ls.q, ls.A, ls.l, ls.u)
     qp.close()
+
+
+# ---------------------------------------------------------------------------------------------- golden fixtures
+from tests.support import golden  # noqa: E402
+
+_FIX = golden.load()
+
+
+@pytest.mark.parametrize("name", golden.NAMES)
+def test_golden_fixtures(built, name):
+    """committed fixtures: same status / iterations / x as the pinned oracle run, and within ADMM accuracy of the
+    KKT-verified optimum"""
+    from optimal_control_problem_amd.batch_qp import solve_local_system
+    f = _FIX[name]
+    got = solve_local_system(f["ls"])
+    assert (got["status"] == f["oracle"]["status"]).all() and (got["iters"] == f["oracle"]["iters"]).all()
+    ok = np.isfinite(f["oracle"]["x"])
+    assert (np.isfinite(got["x"]) == ok).all()
+    if ok.any():
+        assert np.abs(got["x"][ok] - f["oracle"]["x"][ok]).max() <= RTOL * (1 + np.abs(f["oracle"]["x"][ok]).max())
+        assert np.abs(got["y"][np.isfinite(f["oracle"]["y"])] - f["oracle"]["y"][np.isfinite(f["oracle"]["y"])]).max() <= RTOL * (1 + np.abs(f["oracle"]["y"][np.isfinite(f["oracle"]["y"])]).max())
+    if np.isfinite(f["x_star"]).all():
+        tight = solve_local_system(f["ls"], eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+        assert (tight["status"] == 1).all()
+        assert np.abs(tight["x"] - f["x_star"]).max() <= 1e-5 * (1 + np.abs(f["x_star"]).max())
+
+
+# ---------------------------------------------------------------------------------------------- host API on the GPU
+def test_cucaqp_call_sequence_and_errors(built, capsys):
+    """setDimension -> settings -> setSystem -> initSolver -> solve -> getSolution (reference
+    SQPOptimizationSolver.cpp:80-85,155-167); bool + stderr error behaviour of CuCaQP.cpp:23-27,49-52,199-203"""
+    from optimal_control_problem_amd.cucaqp import CuCaQP
+    mdl, arg, expected = models.reference_test_cases()[0]
+    ls = problems.toy_local_system(mdl, arg)
+    qp = CuCaQP()
+    assert qp.setDimension(0, 3) is False and "Invalid dimensions" in capsys.readouterr().err
+    assert qp.solve() is False and "not initialized" in capsys.readouterr().err
+    assert qp.setDimension(ls.n, ls.m) is True
+    qp.setVerbosity(False); qp.setWarmStart(True); qp.setAbsoluteTolerance(1e-3); qp.setRelativeTolerance(1e-3); qp.setMaxIteration(10000)
+    assert qp.setGradient(np.zeros(ls.n + 1)) is False and "size mismatch" in capsys.readouterr().err
+    qp.setSystem([(ls.Pp, ls.Pi, ls.P[0]), ls.q[0], (ls.Ap, ls.Ai, ls.A[0]), ls.l[0], ls.u[0]])
+    assert qp.initSolver() is True and qp.solve() is True
+    assert np.abs(qp.getSolution()[0] - expected).max() < 5e-3
+    assert qp.getStatus()[0] == 1 and qp.getIterations()[0] == 25
+    qp.printSolverData()
+    assert "scaling c" in capsys.readouterr().out
+    qp.close()
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_sqp_driver_on_gpu_testcpp(built, idx):
+    """the reference's SQP outer loop over the GPU QP: expected optima of test/test.cpp cases 1-7"""
+    from optimal_control_problem_amd.sqp import SQPOptimizationSolver
+    mdl, arg, expected = models.reference_test_cases()[idx]
+    s = SQPOptimizationSolver(mdl, {"max_iter": 3, "alpha": 1.0, "verbose": False})
+    res = s.getOptimalSolution({k: np.asarray(v, float) for k, v in arg.items()})
+    assert np.abs(res["x"][0] - np.asarray(expected)).max() < 5e-3
+    s.qpSolver_.close()
+
+
+def test_sqp_driver_gpu_equals_oracle_backend(built):
+    """batched nonlinear MPC tick (quadrotor, 10 damped SQP steps as the reference defaults): GPU QP backend and
+    oracle backend produce the same trajectory"""
+    from optimal_control_problem_amd.sqp import SQPOptimizationSolver
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 8
+    mdl, ls, meta = models.make_workload("quadrotor", B, N=10)
+    arg = dict(lbx=meta["lbx"], ubx=meta["ubx"], lbg=meta["lbg"], ubg=meta["ubg"], p=meta["p"])
+    a = SQPOptimizationSolver(mdl, {"max_iter": 10, "alpha": 0.5}, batch=B)
+    b = SQPOptimizationSolver(mdl, {"max_iter": 10, "alpha": 0.5}, batch=B, qp_solver=OracleCuCaQP(batch=B))
+    ra = a.getOptimalSolution(arg); rb = b.getOptimalSolution(arg)
+    assert np.abs(ra["x"] - rb["x"]).max() <= 1e-6 * (1 + np.abs(rb["x"]).max())
+    assert np.abs(mdl.constraints(ra["x"])).max() < np.abs(mdl.constraints(np.zeros_like(ra["x"]))).max()
+    a.qpSolver_.close()
+
+
+# ---------------------------------------------------------------------------------------------- full size
+def test_full_size_quadrotor_properties(built):
+    """BASELINE.json north-star size (12-state quadrotor, N = 20, batch 8192): size-independent properties --
+    every instance solved, batch-order independence (bitwise), duplicated instances identical, returned (x, y, z)
+    satisfy the unscaled termination test recomputed on the host, and a sample equals the oracle."""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    B = 8192
+    mdl, ls, _ = models.make_workload("quadrotor", B)
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get()
+    assert (got["status"] == 1).all()
+    # reversed order + instance 0 duplicated at the end
+    idx = np.arange(B)[::-1].copy(); idx[-1] = B - 1; idx[0] = B - 1
+    qp.update(ls.P[idx], ls.q[idx], ls.A[idx], ls.l[idx], ls.u[idx]); qp.solve(); rev = qp.get()
+    assert np.array_equal(rev["x"], got["x"][idx]) and np.array_equal(rev["iters"], got["iters"][idx])
+    qp.close()
+    # host recomputation of the residuals from the returned point
+    x, y, z = got["x"], got["y"], got["z"]
+    Ax = np.zeros((B, ls.m)); Aty = np.zeros((B, ls.n)); Px = np.zeros((B, ls.n))
+    for j in range(ls.n):
+        for k in range(ls.Ap[j], ls.Ap[j + 1]):
+            Ax[:, ls.Ai[k]] += ls.A[:, k] * x[:, j]; Aty[:, j] += ls.A[:, k] * y[:, ls.Ai[k]]
+        for k in range(ls.Pp[j], ls.Pp[j + 1]):
+            if ls.Pi[k] <= j:
+                Px[:, ls.Pi[k]] += ls.P[:, k] * x[:, j]
+                if ls.Pi[k] != j:
+                    Px[:, j] += ls.P[:, k] * x[:, ls.Pi[k]]
+    prim = np.abs(Ax - z).max(axis=1); dual = np.abs(Px + ls.q + Aty).max(axis=1)
+    eps_p = 1e-3 + 1e-3 * np.maximum(np.abs(Ax).max(axis=1), np.abs(z).max(axis=1))
+    eps_d = 1e-3 + 1e-3 * np.maximum(np.abs(Px).max(axis=1), np.maximum(np.abs(Aty).max(axis=1), np.abs(ls.q).max(axis=1)))
+    assert (prim <= eps_p * (1 + 1e-9)).all() and (dual <= eps_d * (1 + 1e-9)).all()
+    assert np.abs(prim - got["prim_res"]).max() < 1e-9 and np.abs(dual - got["dual_res"]).max() < 1e-7
+    lo = np.maximum(ls.l, -1e30); hi = np.minimum(ls.u, 1e30)
+    assert (z >= lo - 1e-9).all() and (z <= hi + 1e-9).all()          # z is a projection onto [l, u]
+    sl = slice(0, 64)
+    sub = models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[sl], ls.q[sl], ls.A[sl], ls.l[sl], ls.u[sl])
+    ref = problems.oracle_solve(sub)
+    assert (ref["iters"] == got["iters"][sl]).all()
+    assert np.abs(ref["x"] - got["x"][sl]).max() < 1e-6

@@ -1,0 +1,69 @@
+"""CPU: host-side plan (ordering, ELL layouts, block pattern, assembly recipe, factor op list, block streams)
+executed by the scalar interpreter in tests/support/plan_interp.cpp and compared with dense linear algebra."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from optimal_control_problem_amd import models
+from tests.support import problems
+
+SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "libplan_interp.so")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _run(ls, b=0, force=-1, seed=0):
+    L = C.CDLL(SO)
+    rng = np.random.default_rng(seed)
+    n, m = ls.n, ls.m
+    info = np.zeros(8, np.int64); pos = np.zeros(n, np.int32)
+    assert L.plan_describe(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), force, _p(info), _p(pos)) == 0
+    assert sorted(pos.tolist()) == list(range(n))
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); xin = rng.normal(size=n); win = rng.normal(size=m)
+    sol = np.zeros(n); Ax = np.zeros(m); Atw = np.zeros(n); Px = np.zeros(n)
+    Pv = np.ascontiguousarray(ls.P[b]); Av = np.ascontiguousarray(ls.A[b])
+    rc = L.plan_execute(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), force, _p(Pv), _p(Av), _p(rho), C.c_double(sigma),
+                        _p(rhs), _p(sol), _p(xin), _p(win), _p(Ax), _p(Atw), _p(Px))
+    assert rc == 0
+    ref = np.linalg.solve(M, rhs)
+    rel = lambda a, r: np.abs(a - r).max() / max(np.abs(r).max(), 1e-300)
+    assert rel(sol, ref) < 1e-9
+    assert rel(Ax, Ad @ xin) < 1e-13 and rel(Atw, Ad.T @ win) < 1e-13 and rel(Px, Pd @ xin) < 1e-13
+    return dict(npad=info[0], mpad=info[1], nb=info[2], nblk=info[3], nT=info[4], nfac=info[5], ordering=info[6], lds=info[7])
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_plan_toy(built, idx):
+    mdl, arg, _ = models.reference_test_cases()[idx]
+    info = _run(problems.toy_local_system(mdl, arg))
+    assert info["nblk"] == 1
+
+
+@pytest.mark.parametrize("name,N,blocks", [("double_integrator", 20, 9), ("quadrotor", 20, 60), ("cartpole", 30, None), ("quadrotor", 50, 150)])
+def test_plan_stage_models(built, name, N, blocks):
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    info = _run(ls, 1)
+    assert info["ordering"] == 1                      # the parameter block p is recognised as a hub and moved last
+    if blocks:
+        assert info["nblk"] == blocks                 # block-tridiagonal + arrow, no extra fill
+    nat = _run(ls, 0, force=0)
+    assert nat["nblk"] > info["nblk"]                 # natural order (p first) fills in
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_plan_random(built, seed):
+    _run(problems.random_qp(9 + 11 * seed, 13 + 17 * seed, seed, density=0.2), seed=seed)
+
+
+def test_plan_no_constraints_rows_only_boxes(built):
+    mdl, arg, _ = models.reference_test_cases()[1]    # no g rows: A is the identity
+    info = _run(problems.toy_local_system(mdl, arg))
+    assert info["nT"] == 0

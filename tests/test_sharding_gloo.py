@@ -1,0 +1,66 @@
+"""CPU: the N > 1 path (static batch sharding, timing reduction, final gather) with world_size 2 over gloo.
+The CPU oracle stands in for the per-rank GPU solve; on the GPU box bench.py runs the same helpers over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from optimal_control_problem_amd import models, sharding
+from tests.support import problems
+rank, world, local, dist = sharding.init_distributed(2, backend="gloo")
+assert world == 2
+mdl, ls, _ = models.make_workload("double_integrator", 10, seed=99)
+a, b = sharding.shard_range(ls.batch, rank, world)
+mine = models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[a:b], ls.q[a:b], ls.A[a:b], ls.l[a:b], ls.u[a:b])
+res = problems.oracle_solve(mine)
+sharding.barrier(dist)
+t = sharding.max_over_ranks(1.0 + rank, dist)
+s = sharding.sum_over_ranks(float(b - a), dist)
+x = sharding.gather_rows(res["x"], dist, dst=0)
+if rank == 0:
+    full = problems.oracle_solve(ls)
+    assert t == 2.0 and s == ls.batch
+    assert x.shape == full["x"].shape and np.array_equal(x, full["x"])
+    print("GLOO_OK")
+else:
+    assert x is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions():
+    from optimal_control_problem_amd.sharding import shard_range
+    for total in (1, 7, 8, 8192, 65536):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo(built, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GLOO_OK" in outs[0]
