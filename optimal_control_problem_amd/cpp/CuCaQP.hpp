@@ -1,0 +1,161 @@
+// CuCaQP.hpp -- C++ facade over the C ABI (include/mpcqp.h) with the reference class's public surface.
+//
+// Mirrors reference include/optimal_control_problem/sqp_solver/CuCaQP.h:27-102 so that
+// SQPOptimizationSolver's call sequence (reference src/sqp_solver/SQPOptimizationSolver.cpp:80-85,155-167)
+//     setDimension -> setVerbosity/WarmStart/AbsoluteTolerance/RelativeTolerance/MaxIteration
+//     -> [ setSystem(P,q,A,l,u) -> initSolver -> solve -> getSolution ]  per SQP iteration
+// compiles unchanged against it.  Same bool-return + std::cerr error behaviour (reference
+// src/sqp_solver/CuCaQP.cpp); values stay fp64 (the reference's OSQP build is float, cpu_install.sh:44).
+// The always-available overloads take raw CSC (colptr, rowidx, values) and dense pointers; the CasADi / Eigen
+// overloads of the reference are compiled only where those headers exist (they do not in this image).
+// One object may hold a batch of QPs of one sparsity (value arrays instance-major); batch = 1 is the drop-in case.
+#pragma once
+#include <cstddef>
+#include <iostream>
+#include <vector>
+
+#include "mpcqp.h"
+
+#if defined(__has_include)
+#if __has_include(<casadi/casadi.hpp>)
+#include <casadi/casadi.hpp>
+#define MPCQP_HAVE_CASADI 1
+#endif
+#endif
+
+class CuCaQP {
+ public:
+  struct CscView { int rows, cols; const int *colptr, *rowidx; const double *values; };
+
+  explicit CuCaQP(int batch = 1) : batch_(batch) { mpcqp_default_settings(&settings_); }
+  ~CuCaQP() { clearSolver(); }                                   // reference CuCaQP.cpp:16-21
+  CuCaQP(const CuCaQP &) = delete;
+  CuCaQP &operator=(const CuCaQP &) = delete;
+
+  bool setDimension(int numOfVariables, int numOfConstraints) {  // reference CuCaQP.cpp:23-41
+    if (numOfVariables <= 0 || numOfConstraints <= 0) { std::cerr << "Error: Invalid dimensions." << std::endl; return false; }
+    clearSolver();
+    numOfVariables_ = numOfVariables; numOfConstraints_ = numOfConstraints;
+    return true;
+  }
+
+  // settings pass-through, reference CuCaQP.cpp:163-181
+  void setVerbosity(bool verbosity) { verbose_ = verbosity; }
+  void setWarmStart(bool) {}  // moot in the reference too: setSystem clears the solver (CuCaQP.cpp:271-280)
+  void setAbsoluteTolerance(double tolerance) { settings_.eps_abs = tolerance; dirty_ = true; }
+  void setRelativeTolerance(double tolerance) { settings_.eps_rel = tolerance; dirty_ = true; }
+  void setMaxIteration(int maxIteration) { settings_.max_iter = maxIteration; dirty_ = true; }
+  mpcqp_settings &settings() { dirty_ = true; return settings_; }
+
+  // data, reference CuCaQP.cpp:43-103 (values are copied, like the reference copies into its members CuCaQP.h:83-87)
+  bool setHessianMatrix(const CscView &P) {
+    if (P.rows != numOfVariables_ || P.cols != numOfVariables_) {
+      std::cerr << "Error: Hessian matrix dimensions mismatch. Expected " << numOfVariables_ << "x" << numOfVariables_ << std::endl;
+      return false;
+    }
+    patternChanged_ |= assignPattern(P, Pp_, Pi_);
+    Pv_.assign(P.values, P.values + (size_t)batch_ * Pi_.size());
+    return true;
+  }
+  bool setGradient(const double *q, int size) {
+    if (size != numOfVariables_) { std::cerr << "Error: Gradient vector size mismatch. Expected " << numOfVariables_ << std::endl; return false; }
+    q_.assign(q, q + (size_t)batch_ * size);
+    return true;
+  }
+  bool setLinearConstraintsMatrix(const CscView &A) {
+    if (A.rows != numOfConstraints_ || A.cols != numOfVariables_) {
+      std::cerr << "Error: Constraint matrix dimensions mismatch. Expected " << numOfConstraints_ << "x" << numOfVariables_ << std::endl;
+      return false;
+    }
+    patternChanged_ |= assignPattern(A, Ap_, Ai_);
+    Av_.assign(A.values, A.values + (size_t)batch_ * Ai_.size());
+    return true;
+  }
+  bool setLowerBound(const double *l, int size) {
+    if (size != numOfConstraints_) { std::cerr << "Error: Lower bound vector size mismatch. Expected " << numOfConstraints_ << std::endl; return false; }
+    l_.assign(l, l + (size_t)batch_ * size);
+    return true;
+  }
+  bool setUpperBound(const double *u, int size) {
+    if (size != numOfConstraints_) { std::cerr << "Error: Upper bound vector size mismatch. Expected " << numOfConstraints_ << std::endl; return false; }
+    u_.assign(u, u + (size_t)batch_ * size);
+    return true;
+  }
+  // reference CuCaQP.cpp:271-288 (order P, q, A, l, u); return values dropped like the reference
+  void setSystem(const CscView &P, const double *q, const CscView &A, const double *l, const double *u) {
+    isInitialized_ = false;
+    setHessianMatrix(P); setGradient(q, numOfVariables_); setLinearConstraintsMatrix(A);
+    setLowerBound(l, numOfConstraints_); setUpperBound(u, numOfConstraints_);
+  }
+
+  bool initSolver() {                                            // reference CuCaQP.cpp:183-197
+    isInitialized_ = false;
+    if (Pp_.empty() || Ap_.empty() || q_.empty() || l_.empty() || u_.empty()) { std::cerr << "Error: Failed to initialize solver." << std::endl; return false; }
+    int rc = MPCQP_OK;
+    if (!handle_ || patternChanged_ || dirty_) {
+      clearSolver();
+      rc = mpcqp_create(numOfVariables_, numOfConstraints_, batch_, Pp_.data(), Pi_.data(), Ap_.data(), Ai_.data(), &settings_, &handle_);
+      patternChanged_ = dirty_ = false;
+    }
+    if (rc == MPCQP_OK)
+      rc = mpcqp_update(handle_, Pv_.data(), (long)Pi_.size(), q_.data(), numOfVariables_, Av_.data(), (long)Ai_.size(),
+                        l_.data(), numOfConstraints_, u_.data(), numOfConstraints_, MPCQP_MEM_HOST);
+    if (rc != MPCQP_OK) { std::cerr << "Error: Failed to initialize solver. (" << mpcqp_strerror(rc) << ")" << std::endl; return false; }
+    isInitialized_ = true;
+    return true;
+  }
+
+  bool solve() {                                                 // reference CuCaQP.cpp:199-211
+    if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
+    int rc = mpcqp_solve(handle_, nullptr);
+    solution_.resize((size_t)batch_ * numOfVariables_); status_.resize(batch_); iters_.resize(batch_);
+    if (rc == MPCQP_OK) rc = mpcqp_get(handle_, solution_.data(), nullptr, nullptr, status_.data(), iters_.data(), nullptr, MPCQP_MEM_HOST);
+    if (rc != MPCQP_OK) { std::cerr << "Error: Failed to solve problem. Error code: " << rc << std::endl; return false; }
+    if (verbose_) std::cout << "mpcqp: status " << status_[0] << " after " << iters_[0] << " ADMM iterations" << std::endl;
+    return true;
+  }
+
+  const std::vector<double> &getSolution() const { return solution_; }   // reference CuCaQP.cpp:213-215
+  const std::vector<int> &getStatus() const { return status_; }
+  const std::vector<int> &getIterations() const { return iters_; }
+
+  void printSolverData() const {                                 // reference CuCaQP.cpp:226-269
+    std::cout << "q:"; for (int i = 0; i < numOfVariables_; i++) std::cout << " " << q_[i]; std::cout << std::endl;
+    std::cout << "l:"; for (int i = 0; i < numOfConstraints_; i++) std::cout << " " << l_[i]; std::cout << std::endl;
+    std::cout << "u:"; for (int i = 0; i < numOfConstraints_; i++) std::cout << " " << u_[i]; std::cout << std::endl;
+    for (int j = 0; j < numOfVariables_; j++) for (int p = Pp_[j]; p < Pp_[j + 1]; p++) std::cout << "P(" << Pi_[p] << "," << j << "): " << Pv_[p] << std::endl;
+    for (int j = 0; j < numOfVariables_; j++) for (int p = Ap_[j]; p < Ap_[j + 1]; p++) std::cout << "A(" << Ai_[p] << "," << j << "): " << Av_[p] << std::endl;
+  }
+
+#ifdef MPCQP_HAVE_CASADI
+  // CasADi overloads of the reference (CuCaQP.h:38-48, converters CuCaQP.h:105-152): DM is CSC already.
+  static std::vector<int> toInt(const casadi_int *p, casadi_int n) { return std::vector<int>(p, p + n); }
+  void setSystem(casadi::DMVector sys) {
+    const casadi::DM &P = sys[0], &A = sys[2];
+    pc_ = toInt(P.sparsity().colind(), P.size2() + 1); pr_ = toInt(P.sparsity().row(), P.nnz());
+    ac_ = toInt(A.sparsity().colind(), A.size2() + 1); ar_ = toInt(A.sparsity().row(), A.nnz());
+    setSystem(CscView{(int)P.size1(), (int)P.size2(), pc_.data(), pr_.data(), P.ptr()}, sys[1].ptr(),
+              CscView{(int)A.size1(), (int)A.size2(), ac_.data(), ar_.data(), A.ptr()}, sys[3].ptr(), sys[4].ptr());
+  }
+  casadi::DM getSolutionAsDM() const { return casadi::DM(std::vector<double>(solution_.begin(), solution_.begin() + numOfVariables_)); }
+#endif
+
+ private:
+  bool assignPattern(const CscView &M, std::vector<int> &cp, std::vector<int> &ri) {
+    std::vector<int> ncp(M.colptr, M.colptr + M.cols + 1), nri(M.rowidx, M.rowidx + M.colptr[M.cols]);
+    bool changed = ncp != cp || nri != ri;
+    cp.swap(ncp); ri.swap(nri);
+    return changed;
+  }
+  void clearSolver() { if (handle_) { mpcqp_destroy(handle_); handle_ = nullptr; } isInitialized_ = false; }
+
+  int batch_ = 1, numOfVariables_ = 0, numOfConstraints_ = 0;
+  bool isInitialized_ = false, verbose_ = false, patternChanged_ = true, dirty_ = false;
+  mpcqp_settings settings_;
+  mpcqp_handle *handle_ = nullptr;
+  std::vector<int> Pp_, Pi_, Ap_, Ai_, status_, iters_;
+  std::vector<double> Pv_, Av_, q_, l_, u_, solution_;
+#ifdef MPCQP_HAVE_CASADI
+  std::vector<int> pc_, pr_, ac_, ar_;
+#endif
+};

@@ -1,0 +1,23 @@
+"""The C++ CuCaQP facade (optimal_control_problem_amd/cpp/CuCaQP.hpp) over the C ABI, as a compiled program."""
+import os
+import subprocess
+
+import pytest
+
+EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "cucaqp_cpp_test")
+
+
+def test_cpp_facade_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; see the gpu-marked test")
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)       # refused loudly, no CPU fallback
+    assert "Invalid dimensions" in r.stderr and "not initialized" in r.stderr and "no usable gfx950 GPU" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_facade_on_gpu(built):
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "status 1 iters 25" in r.stdout
