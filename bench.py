@@ -67,8 +67,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="QP instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=None, help="QPs timed on the host for cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
+    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8"])
+    ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
     args = ap.parse_args()
 
+    if args.variant:
+        os.environ["MPCQP_VARIANT"] = args.variant
     import torch
     from optimal_control_problem_amd import models, sharding
     from optimal_control_problem_amd.batch_qp import BatchQP
@@ -93,7 +98,10 @@ def main():
     oy = torch.empty(batch, ls.m, dtype=torch.float64, device=dev)
     ost = torch.empty(batch, dtype=torch.int32, device=dev)
     oit = torch.empty(batch, dtype=torch.int32, device=dev)
-    qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, device=local)
+    kw = dict(device=local)
+    if args.force_iters:
+        kw.update(max_iter=args.force_iters, eps_abs=0.0, eps_rel=0.0, eps_prim_inf=0.0, eps_dual_inf=0.0, adaptive_rho=0)
+    qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, **kw)
     pinfo = qp.plan_info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -144,14 +152,15 @@ def main():
                        "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
+                         "kernel": "mpcqp_res_kernel" if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
                          "algorithmic_bytes_per_solve": abytes},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
                             "admm_iters_per_s": iters_sum / (kms_max * 1e-3),
                             "lds_bytes_per_qp": pinfo["lds_bytes"], "workspace_bytes_per_qp": pinfo["workspace_bytes_per_qp"],
-                            "L_blocks": pinfo["L_blocks"], "workload_gen_s": t_gen},
+                            "L_blocks": pinfo["L_blocks"], "workload_gen_s": t_gen,
+                            "kernel_variant": {0: "stream (1 wave/QP, factor streamed from HBM)"}.get(pinfo["variant"], "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_iters:
             # the oracle (CPU port of the same algorithm) on this box's host cores, bounded sample of the same workload
             from oracle import oracle as orc
             cores = int(os.environ.get("MPCQP_CPU_THREADS", "0")) or host_cores()

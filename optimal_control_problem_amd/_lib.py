@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmpcqp.so")
+SO_PATH = os.environ.get("MPCQP_LIB") or os.path.join(_HERE, "libmpcqp.so")   # MPCQP_LIB: diagnostic builds only
 _LIB = None
 
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -130,7 +130,7 @@ class BatchQP:
         a = np.zeros(16, dtype=np.int64)
         _lib.check(_lib.lib().mpcqp_plan_info(self._h, a.ctypes.data))
         keys = ["n", "m", "batch", "npad", "mpad", "n_blocks", "L_blocks", "lds_bytes", "workspace_bytes_per_qp",
-                "ordering", "nnzP_triu", "nnzA", "T_blocks", "factor_ops", "ell_slots", "reserved"]
+                "ordering", "nnzP_triu", "nnzA", "T_blocks", "factor_ops", "ell_slots", "variant"]
         return dict(zip(keys, a.tolist()))
 
     def debug_scaling(self, b=0):

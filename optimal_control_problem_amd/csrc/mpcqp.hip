@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,7 +54,7 @@ struct DevIO {
   const double *P, *q, *A, *l, *u; long sP, sq, sA, sl, su;
   const double *x0, *y0;
   double *x, *y, *z; int *status, *iters; double *info;
-  double *ws; double *cscale;
+  double *ws; double *cscale; long long *dbg;
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -195,6 +196,7 @@ __device__ __forceinline__ void stream_step(const d4 bb, const int op, double *v
 __device__ void run_stream(const double *__restrict__ blk, const int *__restrict__ ops, const int nops, double *vec) {
   const int lane = threadIdx.x, r = lane >> 2, j = lane & 3;
   const d4 *p = reinterpret_cast<const d4 *>(blk) + lane;
+  // 4 blocks (8 KiB) of the stream in flight per wave; 8 measured slower on MI355X (profiles/r01 notes)
   d4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
   if (0 < nops) b0 = p[0];
   if (1 < nops) b1 = p[WAVE];
@@ -594,6 +596,694 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
   }
 }
 
+
+// =========================================================================================================
+// Resident variant: NW waves per QP, block LDL' factor (G_J = D_J^-1, W_IJ) held in LDS for the whole solve.
+// HBM is touched per iteration only for the ELL sweeps of A / A' (L2-resident per-QP slabs) and l, u.
+// =========================================================================================================
+#ifdef MPCQP_TIMING
+#define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[16] = {0}
+#define TS(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[k] += t_ - ts_last; ts_last = t_; } while (0)
+#define TS_STORE(ptr) do { if (tid == 0 && (ptr)) for (int k_ = 0; k_ < 16; k_++) (ptr)[16L * b + k_] = (long long)ts_acc[k_]; } while (0)
+#else
+#define TS_DECL
+#define TS(k)
+#define TS_STORE(ptr)
+#endif
+struct DevRes {
+  int nphase, ntemp;
+  const int *col_diag, *w_ptr, *w_slot, *u_ptr, *u_dst, *u_tmp, *u_b, *g_ptr, *g_seg;
+  int n_seg;
+};
+
+template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
+
+struct RCtx {
+  const DevPlan *pl; const DevRes *rs; const mpcqp_settings *st; double *ws;
+  double *BL, *TMP, *X, *Q, *R, *Z, *Y, *W, *RB, *RED;
+  double c, cinv, rho; int unscale; int wid, lane;
+  unsigned long long fts[4];
+};
+
+// reduce K per-thread values over the workgroup: the first K - NSUM by max, the last NSUM by sum
+template <int NW, int K, int NSUM>
+__device__ __forceinline__ void block_combine(double (&v)[K], double *red, int wid, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = k >= K - NSUM ? wave_sum(v[k]) : wave_max(v[k]);
+  if (NW > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) red[wid * K + k] = v[k];
+    }
+    bsync<NW>();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      double r = red[k];
+      for (int w = 1; w < NW; w++) r = k >= K - NSUM ? r + red[w * K + k] : fmax(r, red[w * K + k]);
+      v[k] = r;
+    }
+    bsync<NW>();
+  }
+}
+
+template <int NW, class F>
+__device__ __forceinline__ void ell_rows_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  for (int c = wid; c < E.nchunks; c += NW) {
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 8
+    for (int s = s0; s < s1; s++) {
+      const long e = (long)s * WAVE + lane;
+      acc += val[e] * in[E.idx[e]];
+    }
+    f(c * WAVE + lane, acc);
+  }
+}
+template <int NW, class F>
+__device__ __forceinline__ void ell_rowmax_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  for (int c = wid; c < E.nchunks; c += NW) {
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 8
+    for (int s = s0; s < s1; s++) {
+      const long e = (long)s * WAVE + lane;
+      acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
+    }
+    f(c * WAVE + lane, acc);
+  }
+}
+
+// sum over the 4 lanes of a quad with DPP quad_perm (no LDS crossbar round trip)
+__device__ __forceinline__ double quad_sum(double v) {
+  union { double d; int i[2]; } a, t;
+  a.d = v;
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true);
+  a.d += t.d;
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true);
+  return a.d + t.d;
+}
+
+__device__ __forceinline__ double quad_max(double v) {
+  union { double d; int i[2]; } a, t;
+  a.d = v;
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true);
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true);
+  a.d = fmax(a.d, t.d);
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true);
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true);
+  return fmax(a.d, t.d);
+}
+
+// ELL sweeps with 4 lanes per row: a wave covers 16 rows per step, lane group g takes slots s0+g, s0+g+4, ...;
+// every load of a row is in flight at once (one L2 round trip per step) and the row sum is a quad DPP reduction.
+// f(row, value) runs on the g == 0 lane of each row only.
+template <int NW, class F>
+__device__ __forceinline__ void ell_rows_q(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  const int rr = lane >> 2, g = lane & 3;
+  for (int st = wid; st < 4 * E.nchunks; st += NW) {
+    const int c = st >> 2, row = (st & 3) * 16 + rr;
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int s = s0 + g; s < s1; s += 4) {
+      const long e = (long)s * WAVE + row;
+      acc += val[e] * in[E.idx[e]];
+    }
+    acc = quad_sum(acc);
+    if (g == 0) f(c * WAVE + row, acc);
+  }
+}
+template <int NW, class F>
+__device__ __forceinline__ void ell_rowmax_q(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  const int rr = lane >> 2, g = lane & 3;
+  for (int st = wid; st < 4 * E.nchunks; st += NW) {
+    const int c = st >> 2, row = (st & 3) * 16 + rr;
+    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int s = s0 + g; s < s1; s += 4) {
+      const long e = (long)s * WAVE + row;
+      acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
+    }
+    acc = quad_max(acc);
+    if (g == 0) f(c * WAVE + row, acc);
+  }
+}
+
+// acc += A * B^T, operands row-major 16x16 tiles (LDS or global), lane = lane within the wave
+__device__ __forceinline__ d4 mfma_abt_l(const double *A, const double *B, d4 acc, int lane) {
+  const int rr = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < BS; k0 += 4) {
+    const double a = A[rr * BS + k0 + kk];
+    const double b = B[rr * BS + k0 + kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// One wave: in-place inverse of the SPD 16x16 tile `a` (LDS, row-major) by symmetric sweeps; rb = 16 doubles of LDS.
+// Pivots of the sweeps are the Cholesky pivots squared, so "all pivots > 0" is the positive-definiteness test.
+__device__ bool sweep_inverse(double *a, double *rb, int lane) {
+  const int r = lane >> 2, j = lane & 3;
+  d4 v = reinterpret_cast<const d4 *>(a)[lane];      // a[r][4j .. 4j+3]
+#pragma unroll
+  for (int k = 0; k < BS; k++) {
+    if (r == k) reinterpret_cast<d4 *>(rb)[j] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const d4 rk = reinterpret_cast<const d4 *>(rb)[j];
+    const double colk = rb[r], d = rb[k];
+    if (!(d > 0.0)) return false;                       // uniform
+    const double p = 1.0 / d;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int col = 4 * j + c;
+      double nv;
+      if (r != k && col != k) nv = v[c] - colk * rk[c] * p;
+      else if (r == k && col != k) nv = rk[c] * p;
+      else if (r != k && col == k) nv = colk * p;
+      else nv = -p;
+      v[c] = nv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  reinterpret_cast<d4 *>(a)[lane] = -v;
+  return true;
+}
+
+// ---- solve-schedule executor -------------------------------------------------------------------------------
+// A lone wave issues roughly one instruction per 4-8 cycles, so the executor is written for instruction count:
+// the host compresses each wave's op list into segments whose block / src / dst byte offsets are arithmetic
+// progressions; each segment is one tight, branch-free, software-pipelined loop (4 lanes per output row; the next
+// op's 4 block entries and old destination value are fetched while the current op is reduced with a quad DPP sum).
+template <bool T>
+__device__ __forceinline__ d4 load_blk(const char *BLb, const int off, const int offN, const int offT) {
+  if (T) {
+    const char *B = BLb + off + offT;
+    d4 r;
+    r[0] = *reinterpret_cast<const double *>(B); r[1] = *reinterpret_cast<const double *>(B + BS * 8);
+    r[2] = *reinterpret_cast<const double *>(B + 2 * BS * 8); r[3] = *reinterpret_cast<const double *>(B + 3 * BS * 8);
+    return r;
+  }
+  return *reinterpret_cast<const d4 *>(BLb + off + offN);
+}
+__device__ __forceinline__ void wave_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// every op writes its own destination: dst_k = (SET ? 0 : dst_k) -/+ B_k * src_k ; `carry` joins the first op
+template <bool T, bool SET>
+__device__ __forceinline__ void seg_each(const char *BLb, char *vecb, int b, int s, int d, const int cnt, const int db, const int ds, const int dd,
+                                         const int offN, const int offT, const int offV, const int offD, const int j, double carry) {
+  d4 bb = load_blk<T>(BLb, b, offN, offT);
+  double old = SET ? 0.0 : *reinterpret_cast<const double *>(vecb + d + offD);
+  for (int k = 0; k < cnt; k++) {
+    const d4 v = *reinterpret_cast<const d4 *>(vecb + s + offV);
+    d4 nb = bb; double nold = old;
+    if (k + 1 < cnt) {
+      nb = load_blk<T>(BLb, b + db, offN, offT);
+      if (!SET) nold = *reinterpret_cast<const double *>(vecb + d + dd + offD);
+    }
+    const double sum = quad_sum(carry + (bb[0] * v[0] + bb[1] * v[1] + bb[2] * v[2] + bb[3] * v[3]));
+    carry = 0.0;
+    if (j == 0) *reinterpret_cast<double *>(vecb + d + offD) = SET ? sum : old - sum;
+    wave_order();
+    bb = nb; old = nold; b += db; s += ds; d += dd;
+  }
+}
+// the ops accumulate into one destination; returns the per-lane partial sum
+template <bool T>
+__device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int b, int s, const int cnt, const int db, const int ds,
+                                          const int offN, const int offT, const int offV, double acc) {
+#pragma unroll 2
+  for (int k = 0; k < cnt; k++) {
+    const d4 bb = load_blk<T>(BLb, b, offN, offT);
+    const d4 v = *reinterpret_cast<const d4 *>(vecb + s + offV);
+    acc += bb[0] * v[0] + bb[1] * v[1] + bb[2] * v[2] + bb[3] * v[3];
+    b += db; s += ds;
+  }
+  return acc;
+}
+template <int NW>
+__device__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane) {
+  const int r = lane >> 2, j = lane & 3;
+  const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
+  double acc = 0.0;
+  for (int g = g0; g < g1; g++) {
+    int4 a = segs[2 * g], c = segs[2 * g + 1];
+    const int b0 = __builtin_amdgcn_readfirstlane(a.x), s0 = __builtin_amdgcn_readfirstlane(a.y), d0 = __builtin_amdgcn_readfirstlane(a.z);
+    const int fl = __builtin_amdgcn_readfirstlane(a.w), cnt = __builtin_amdgcn_readfirstlane(c.x);
+    const int db = __builtin_amdgcn_readfirstlane(c.y), ds = __builtin_amdgcn_readfirstlane(c.z), dd = __builtin_amdgcn_readfirstlane(c.w);
+    if (fl & SG_NOP) { bsync<NW>(); continue; }
+    if (fl & SG_EACH) {
+      if (fl & SG_SET) seg_each<false, true>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, 0.0);
+      else if (fl & SG_T) seg_each<true, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      else seg_each<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      acc = 0.0;
+    } else {
+      acc = (fl & SG_T) ? seg_run<true>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc)
+                        : seg_run<false>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc);
+      if (fl & SG_END) {
+        const double sum = quad_sum(acc);
+        acc = 0.0;
+        if (j == 0) { double *o = reinterpret_cast<double *>(vecb + d0 + offD); *o = *o - sum; }
+        wave_order();
+      }
+    }
+    if (fl & SG_BAR) bsync<NW>();
+  }
+}
+
+template <int NW>
+__device__ bool factorize_res(RCtx &cx) {
+  const DevPlan &pl = *cx.pl; const DevRes &rs = *cx.rs; double *ws = cx.ws;
+  const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u;
+  const double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  double *T = ws + pl.o_T;
+#ifdef MPCQP_TIMING
+  unsigned long long f0 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) : 0.0;
+  for (long k = tid; k < (long)pl.nT * BLK; k += NT) T[k] = 0.0;
+  bsync<NW>();
+  {
+    const double sigma = cx.st->sigma;
+    const DevEll &E = pl.At;
+    for (int c = wid; c < E.nchunks; c += NW) {
+      double acc = 0.0;
+      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+        const long e = (long)s * WAVE + lane;
+        const double v = valAt[e];
+        if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
+      }
+      const int t = c * WAVE + lane;
+      if (t < pl.npad) cx.R[t] = pl.perm[t] >= 0 ? sigma + acc : 1.0;
+    }
+  }
+  {
+    const DevEll &E = pl.A;
+    for (int c = wid; c < E.nchunks; c += NW) {
+      const int i = c * WAVE + lane;
+      const double sr = sqrt(cx.W[i]);
+      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+        const long e = (long)s * WAVE + lane;
+        const int tp = pl.tpos[e];
+        if (tp >= 0) T[tp] = valA[e] * sr;
+      }
+    }
+  }
+  bsync<NW>();
+#ifdef MPCQP_TIMING
+  unsigned long long f1 = __builtin_amdgcn_s_memtime(); cx.fts[0] += f1 - f0;
+#endif
+  const int row0 = lane >> 4, col = lane & 15;
+  for (int b = wid; b < pl.nblk; b += NW) {
+    d4 acc = {0, 0, 0, 0};
+    for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) acc = mfma_abt_l(T + (long)pl.asm_a[g] * BLK, T + (long)pl.asm_b[g] * BLK, acc, lane);
+    const int J = pl.blk_diag[b];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int pi = pl.asm_pidx[(long)b * BLK + g * WAVE + lane];
+      if (pi >= 0) acc[g] += valP[pi];
+      const int row = row0 + 4 * g;
+      if (J >= 0 && row == col) acc[g] += cx.R[J * BS + row];
+      cx.BL[(long)b * BLK + row * BS + col] = acc[g];
+    }
+  }
+  bsync<NW>();
+#ifdef MPCQP_TIMING
+  unsigned long long f2 = __builtin_amdgcn_s_memtime(); cx.fts[1] += f2 - f1;
+#endif
+  // right-looking block LDL': G_K = S_KK^-1 ; W_IK = S_IK G_K ; S_IJ -= W_IK S_JK'
+  int nprev = 0, prev0 = 0;
+  for (int K = 0; K < pl.nb; K++) {
+    if (wid == 0) {
+      const bool ok = sweep_inverse(cx.BL + (long)rs.col_diag[K] * BLK, cx.RB, lane);
+      if (lane == 0) cx.RB[16] = ok ? 1.0 : 0.0;
+    }
+    if (NW > 1 && wid > 0) {     // deferred: previous column's W tiles -> their slots
+      for (int a = wid - 1; a < nprev; a += NW - 1)
+        reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+    }
+    bsync<NW>();
+    if (cx.RB[16] == 0.0) return false;
+    const int w0 = rs.w_ptr[K], nwk = rs.w_ptr[K + 1] - w0;
+    const double *G = cx.BL + (long)rs.col_diag[K] * BLK;
+    for (int a = wid; a < nwk; a += NW) {
+      d4 acc = {0, 0, 0, 0};
+      acc = mfma_abt_l(cx.BL + (long)rs.w_slot[w0 + a] * BLK, G, acc, lane);
+      double *t = cx.TMP + (long)a * BLK;
+#pragma unroll
+      for (int g = 0; g < 4; g++) t[(row0 + 4 * g) * BS + col] = acc[g];
+    }
+    bsync<NW>();
+    for (int u = rs.u_ptr[K] + wid; u < rs.u_ptr[K + 1]; u += NW) {
+      d4 acc = {0, 0, 0, 0};
+      acc = mfma_abt_l(cx.TMP + (long)rs.u_tmp[u] * BLK, cx.BL + (long)rs.u_b[u] * BLK, acc, lane);
+      double *dst = cx.BL + (long)rs.u_dst[u] * BLK;
+#pragma unroll
+      for (int g = 0; g < 4; g++) dst[(row0 + 4 * g) * BS + col] -= acc[g];
+    }
+    bsync<NW>();
+    if (NW == 1) {
+      for (int a = 0; a < nwk; a++)
+        reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[w0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+      bsync<NW>();
+    }
+    nprev = nwk; prev0 = w0;
+  }
+  if (NW > 1) {                  // the last column has no off-diagonal block, but flush defensively
+    for (int a = wid; a < nprev; a += NW)
+      reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+  }
+  for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
+  bsync<NW>();
+#ifdef MPCQP_TIMING
+  cx.fts[2] += __builtin_amdgcn_s_memtime() - f2;
+#endif
+  return true;
+}
+
+template <int NW>
+__device__ void update_info_res(RCtx &cx, Info &in) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane;
+  const double *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
+  const double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  const int unscale = cx.unscale;
+  double v[15];
+#pragma unroll
+  for (int k = 0; k < 15; k++) v[k] = 0.0;
+  // 0 pr 1 nz 2 nax 3 prs 4 nzs 5 naxs 6 dr 7 nq 8 naty 9 npx 10 drs 11 nqs 12 natys 13 npxs | 14 obj (sum)
+  ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) {
+    if (i < pl.m) {
+      const double einv = unscale ? 1.0 / Eg[i] : 1.0, zi = cx.Z[i];
+      v[0] = fmax(v[0], fabs(einv * (ax - zi))); v[2] = fmax(v[2], fabs(einv * ax)); v[1] = fmax(v[1], fabs(einv * zi));
+      v[3] = fmax(v[3], fabs(ax - zi)); v[5] = fmax(v[5], fabs(ax)); v[4] = fmax(v[4], fabs(zi));
+    }
+  });
+  // P x and A' y land on the same rows for a given wave (both chunked by wid), so no barrier is needed in between
+  for (int c = wid; c < pl.P.nchunks; c += NW) {
+    double px = 0.0, aty = 0.0;
+    for (int s = pl.P.chunk_off[c]; s < pl.P.chunk_off[c + 1]; s++) { const long e = (long)s * WAVE + lane; px += valP[e] * cx.X[pl.P.idx[e]]; }
+#pragma unroll 8
+    for (int s = pl.At.chunk_off[c]; s < pl.At.chunk_off[c + 1]; s++) { const long e = (long)s * WAVE + lane; aty += valAt[e] * cx.Y[pl.At.idx[e]]; }
+    const int t = c * WAVE + lane;
+    if (t < pl.npad) {
+      const double dinv = unscale ? 1.0 / Dg[t] : 1.0, qv = cx.Q[t], du = qv + px + aty;
+      v[6] = fmax(v[6], fabs(dinv * du)); v[7] = fmax(v[7], fabs(dinv * qv)); v[8] = fmax(v[8], fabs(dinv * aty)); v[9] = fmax(v[9], fabs(dinv * px));
+      v[10] = fmax(v[10], fabs(du)); v[11] = fmax(v[11], fabs(qv)); v[12] = fmax(v[12], fabs(aty)); v[13] = fmax(v[13], fabs(px));
+      v[14] += cx.X[t] * (0.5 * px + qv);
+    }
+  }
+  block_combine<NW, 15, 1>(v, cx.RED, wid, lane);
+  in.prim_res = v[0]; in.nz = v[1]; in.nax = v[2]; in.prs = v[3]; in.nzs = v[4]; in.naxs = v[5];
+  in.dual_res = unscale ? cx.cinv * v[6] : v[6]; in.nq = v[7]; in.naty = v[8]; in.npx = v[9];
+  in.drs = v[10]; in.nqs = v[11]; in.natys = v[12]; in.npxs = v[13];
+  in.obj = cx.st->scaling ? cx.cinv * v[14] : v[14];
+}
+
+template <int NW>
+__device__ bool primal_infeasible_res(RCtx &cx, double eps) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dy = ws + pl.o_dy;
+  double v[2] = {0.0, 0.0};   // 0 nrm (max) 1 lhs (sum)
+  for (int i = tid; i < pl.mpad; i += NT) {
+    double x = 0.0;
+    if (i < pl.m) {
+      x = dy[i];
+      const double lo = lb[i], up = ub[i];
+      if (up > Q_INFTY * Q_MIN_SCALING) { if (lo < -Q_INFTY * Q_MIN_SCALING) x = 0.0; else x = fmin(x, 0.0); }
+      else if (lo < -Q_INFTY * Q_MIN_SCALING) x = fmax(x, 0.0);
+      v[0] = fmax(v[0], fabs(cx.unscale ? Eg[i] * x : x));
+      v[1] += up * fmax(x, 0.0) + lo * fmin(x, 0.0);
+    }
+    cx.W[i] = x;
+  }
+  block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
+  if (NW == 1) bsync<NW>();
+  const double nrm = v[0], lhs = v[1];
+  bool res = false;
+  if (nrm > eps && lhs < -eps * nrm) {
+    double a[1] = {0.0};
+    ell_rows_w<NW>(pl.At, ws + pl.o_ellAt, cx.W, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
+    block_combine<NW, 1, 0>(a, cx.RED, wid, lane);
+    res = a[0] < eps * nrm;
+  }
+  bsync<NW>();
+  for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
+  bsync<NW>();
+  return res;
+}
+
+template <int NW>
+__device__ bool dual_infeasible_res(RCtx &cx, double eps) {
+  const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
+  const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dx = ws + pl.o_dx;
+  double v[2] = {0.0, 0.0};   // 0 nrm (max) 1 q'dx (sum)
+  for (int t = tid; t < pl.npad; t += NT) {
+    const double x = dx[t];
+    cx.R[t] = x;
+    v[0] = fmax(v[0], fabs(cx.unscale ? Dg[t] * x : x));
+    v[1] += cx.Q[t] * x;
+  }
+  block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
+  if (NW == 1) bsync<NW>();
+  const double nrm = v[0], qdx = v[1], cs = cx.unscale ? cx.c : 1.0;
+  bool res = false;
+  if (nrm > eps && qdx < -cs * eps * nrm) {
+    double a[1] = {0.0};
+    ell_rows_w<NW>(pl.P, ws + pl.o_ellP, cx.R, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
+    block_combine<NW, 1, 0>(a, cx.RED, wid, lane);
+    if (a[0] < cs * eps * nrm) {
+      double bad[1] = {0.0};
+      ell_rows_w<NW>(pl.A, ws + pl.o_ellA, cx.R, wid, lane, [&](int i, double x) {
+        if (i < pl.m) {
+          if (cx.unscale) x = (1.0 / Eg[i]) * x;
+          if ((ub[i] < Q_INFTY * Q_MIN_SCALING && x > eps * nrm) || (lb[i] > -Q_INFTY * Q_MIN_SCALING && x < -eps * nrm)) bad[0] = 1.0;
+        }
+      });
+      block_combine<NW, 1, 0>(bad, cx.RED, wid, lane);
+      res = bad[0] == 0.0;
+    }
+  }
+  bsync<NW>();
+  return res;
+}
+
+template <int NW>
+__device__ int check_termination_res(RCtx &cx, Info &in, int approximate) {
+  const mpcqp_settings &st = *cx.st;
+  double eps_abs = st.eps_abs, eps_rel = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
+  if (in.prim_res > Q_INFTY || in.dual_res > Q_INFTY || in.prim_res != in.prim_res || in.dual_res != in.dual_res) { in.obj = NAN; return MPCQP_NON_CVX; }
+  if (approximate) { eps_abs *= 10; eps_rel *= 10; epi *= 10; edi *= 10; }
+  bool pc = false, dc = false, pic = false, dic = false;
+  if (cx.pl->m == 0) pc = true;
+  else {
+    const double eps_prim = eps_abs + eps_rel * fmax(in.nz, in.nax);
+    if (in.prim_res < eps_prim) pc = true; else pic = primal_infeasible_res<NW>(cx, epi);
+  }
+  {
+    double mx = fmax(in.nq, fmax(in.naty, in.npx));
+    if (cx.unscale) mx *= cx.cinv;
+    const double eps_dual = eps_abs + eps_rel * mx;
+    if (in.dual_res < eps_dual) dc = true; else dic = dual_infeasible_res<NW>(cx, edi);
+  }
+  if (pc && dc) return approximate ? MPCQP_SOLVED_INACCURATE : MPCQP_SOLVED;
+  if (pic) { in.obj = Q_INFTY; return approximate ? MPCQP_PRIMAL_INFEASIBLE_INACCURATE : MPCQP_PRIMAL_INFEASIBLE; }
+  if (dic) { in.obj = -Q_INFTY; return approximate ? MPCQP_DUAL_INFEASIBLE_INACCURATE : MPCQP_DUAL_INFEASIBLE; }
+  return MPCQP_UNSOLVED;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = NW * WAVE;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RCtx cx;
+  cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
+  cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
+  cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK;
+  cx.X = cx.TMP + (long)rs.ntemp * BLK; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
+  cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
+  cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 64;
+  int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
+  int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
+  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
+  double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
+  const double *inP = io.P + (long)b * io.sP, *inA = io.A + (long)b * io.sA, *inq = io.q + (long)b * io.sq;
+  const double *inl = io.l + (long)b * io.sl, *inu = io.u + (long)b * io.su;
+  const int n = pl.n, m = pl.m, npad = pl.npad, mpad = pl.mpad;
+  cx.unscale = st.scaling && !st.scaled_termination;
+
+  TS_DECL;
+  for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
+  if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
+  for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; valA[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; valAt[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; valP[e] = s >= 0 ? inP[s] : 0.0; }
+  for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
+  for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
+  bsync<NW>();
+  for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
+  bsync<NW>();
+
+  TS(0);
+  // ---- modified Ruiz equilibration: D in R, E in W, temporaries in X / Z
+  double c = 1.0;
+  for (int it = 0; it < st.scaling; it++) {
+    for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+      const int t = ch * WAVE + lane;
+      double nA = 0.0, nP = 0.0;
+#pragma unroll 8
+      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nA = fmax(nA, fabs(valAt[e]) * cx.W[pl.At.idx[e]]); }
+      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nP = fmax(nP, fabs(valP[e]) * cx.R[pl.P.idx[e]]); }
+      if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
+    }
+    ell_rowmax_w<NW>(pl.A, valA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+    bsync<NW>();
+    for (int t = tid; t < npad; t += NT) cx.R[t] *= cx.X[t];
+    for (int i = tid; i < mpad; i += NT) cx.W[i] *= cx.Z[i];
+    bsync<NW>();
+    double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
+    ell_rowmax_w<NW>(pl.P, valP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+    block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
+    const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
+    c *= ct;
+    bsync<NW>();
+  }
+  cx.c = c; cx.cinv = 1.0 / c;
+  TS(1);
+  for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+    const int i = ch * WAVE + lane; const double ei = cx.W[i];
+    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] *= ei * cx.R[pl.A.idx[e]]; }
+  }
+  for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+    const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] *= dj * cx.W[pl.At.idx[e]]; }
+    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] *= c * dj * cx.R[pl.P.idx[e]]; }
+  }
+  bsync<NW>();
+  for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
+  for (int i = tid; i < mpad; i += NT) {
+    const double ei = cx.W[i];
+    Eg[i] = ei;
+    lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
+    ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+  }
+  for (int t = tid; t < npad; t += NT) cx.X[t] = 0.0;
+  for (int i = tid; i < mpad; i += NT) { cx.Z[i] = 0.0; cx.Y[i] = 0.0; }
+  bsync<NW>();
+  if (st.warm_start && io.x0 && io.y0) {
+    for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; cx.X[t] = io.x0[(long)b * n + j] * (1.0 / Dg[t]); }
+    for (int i = tid; i < m; i += NT) cx.Y[i] = io.y0[(long)b * m + i] * (1.0 / Eg[i]) * c;
+    bsync<NW>();
+    ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
+    bsync<NW>();
+  }
+  cx.rho = fmin(fmax(st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  int status = MPCQP_UNSOLVED, iter_done = 0;
+  Info in; memset(&in, 0, sizeof(in));
+  TS(2);
+  const bool ok = factorize_res<NW>(cx);
+  if (!ok) status = MPCQP_NON_CVX;
+  TS(3);
+
+  int interval = st.adaptive_rho_interval;
+  if (st.adaptive_rho && interval == 0) interval = st.check_termination ? 4 * st.check_termination : 100;
+  const double alpha = st.alpha, sigma = st.sigma;
+  double *dxg = ws + pl.o_dx, *dyg = ws + pl.o_dy;
+  int can_check = 0;
+  const int sq0 = lptr[wid], sq1 = lptr[wid + 1];
+  if (ok) {
+    int iter;
+    for (iter = 1; iter <= st.max_iter; iter++) {
+      ell_rows_w<NW>(pl.At, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      bsync<NW>();
+      TS(4);
+#ifdef MPCQP_TIMING
+      long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
+      if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
+      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+      if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
+#else
+      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+#endif
+      if (NW == 1) bsync<NW>();
+      TS(5);
+      can_check = st.check_termination && (iter % st.check_termination == 0);
+      const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
+      const int save = can_check || do_rho;
+      ell_rows_w<NW>(pl.A, valA, cx.R, wid, lane, [&](int i, double zt) {
+        if (i < m) {
+          const double lo = lb[i], up = ub[i], rh = rho_of(lo, up, cx.rho), rinv = 1.0 / rh;
+          const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
+          const double zn = fmin(fmax(zr + rinv * yo, lo), up);
+          const double dy = rh * (zr - zn), yn = yo + dy;
+          cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
+          if (save) dyg[i] = dy;
+        }
+      });
+      bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
+      for (int t = tid; t < npad; t += NT) {
+        const double xo = cx.X[t], xn = alpha * cx.R[t] + (1.0 - alpha) * xo;
+        cx.X[t] = xn;
+        if (save) dxg[t] = xn - xo;
+      }
+      bsync<NW>();
+      TS(6);
+      iter_done = iter;
+      if (can_check) {
+        update_info_res<NW>(cx, in);
+        status = check_termination_res<NW>(cx, in, 0);
+        TS(7);
+        if (status != MPCQP_UNSOLVED) break;
+      }
+      if (do_rho) {
+        if (!can_check) update_info_res<NW>(cx, in);
+        const double pr = in.prs / (fmax(in.nzs, in.naxs) + Q_DIV_TOL);
+        const double dr = in.drs / (fmax(in.nqs, fmax(in.natys, in.npxs)) + Q_DIV_TOL);
+        double rn = cx.rho * sqrt(pr / (dr + Q_DIV_TOL));
+        rn = fmin(fmax(rn, Q_RHO_MIN), Q_RHO_MAX);
+        if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
+          cx.rho = rn;
+          if (!factorize_res<NW>(cx)) { status = MPCQP_NON_CVX; break; }
+        }
+      }
+    }
+    if (iter > st.max_iter) iter_done = st.max_iter;
+    if (status == MPCQP_UNSOLVED) {
+      if (!can_check) { update_info_res<NW>(cx, in); status = check_termination_res<NW>(cx, in, 0); }
+      if (status == MPCQP_UNSOLVED) { status = check_termination_res<NW>(cx, in, 1); if (status == MPCQP_UNSOLVED) status = MPCQP_MAX_ITER_REACHED; }
+    }
+  }
+  const bool bad = status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
+                   status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX;
+  for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; io.x[(long)b * n + j] = bad ? NAN : Dg[t] * cx.X[t]; }
+  for (int i = tid; i < m; i += NT) {
+    io.y[(long)b * m + i] = bad ? NAN : cx.cinv * Eg[i] * cx.Y[i];
+    io.z[(long)b * m + i] = bad ? NAN : (1.0 / Eg[i]) * cx.Z[i];
+  }
+  if (tid == 0) {
+    io.status[b] = status; io.iters[b] = iter_done;
+    io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
+    io.cscale[b] = c;
+  }
+  TS(8);
+#ifdef MPCQP_TIMING
+  ts_acc[12] = cx.fts[0]; ts_acc[13] = cx.fts[1]; ts_acc[14] = cx.fts[2];
+#endif
+  TS_STORE(io.dbg);
+}
+
 // block-primitive self test (mpcqp_debug_blockops)
 extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_blockops_kernel(const double *A, const double *B, const double *C, double *S,
                                                                           double *out_gemm, double *Sb, int *fail) {
@@ -617,12 +1307,15 @@ struct mpcqp_handle {
   int n = 0, m = 0, batch = 0, device = 0;
   mpcqp_settings st;
   Plan plan; WsLayout wl; long lds = 0;
+  int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
+  ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
   double *ws = nullptr;
   double *dP = nullptr, *dq = nullptr, *dA = nullptr, *dl = nullptr, *du = nullptr;  // owned copies (host-memory updates)
   double *dx0 = nullptr, *dy0 = nullptr;
   double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
+  long long *odbg = nullptr;
   bool have_data = false, solved = false;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -707,6 +1400,29 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   const Plan &pl = h->plan;
   h->wl = ws_layout(pl);
   h->lds = lds_bytes(pl);
+  // Variant: keep the factor in LDS when it fits. Small problems take one wave per QP (several QPs per CU);
+  // larger ones that still fit take four waves per QP. MPCQP_VARIANT=stream|res1|res4|res8 overrides.
+  {
+    const long LDS_MAX = 160 * 1024;
+    int want = -1;
+    if (const char *e = getenv("MPCQP_VARIANT")) {
+      std::string v(e);
+      if (v == "stream") want = 0; else if (v == "res1") want = 1; else if (v == "res4") want = 4; else if (v == "res8") want = 8;
+    }
+    ResPlan r1 = build_res_plan(pl, 1);
+    const bool small_ok = pl.nblk < 4096 && pl.nb < 512;
+    if (want < 0) {
+      if (small_ok && lds_bytes_res(pl, r1) <= 40 * 1024) want = 1;
+      else { ResPlan r4 = build_res_plan(pl, 4); want = (small_ok && lds_bytes_res(pl, r4) <= LDS_MAX) ? 4 : 0; }
+    }
+    if (want > 0) {
+      h->rplan = build_res_plan(pl, want);
+      const long need = lds_bytes_res(pl, h->rplan);
+      if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
+      h->lds = need;
+    }
+    h->variant = want;
+  }
   if (h->lds > 160 * 1024) return bail(fail(MPCQP_ERR_LIMIT, "LDS footprint " + std::to_string(h->lds) + " B exceeds 160 KiB per CU"));
   DevPlan &dp = h->dp;
   memset(&dp, 0, sizeof(dp));
@@ -723,6 +1439,13 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   UP(upload(h, pl.tpos, &dp.tpos)); UP(upload(h, pl.asm_ptr, &dp.asm_ptr)); UP(upload(h, pl.asm_a, &dp.asm_a));
   UP(upload(h, pl.asm_b, &dp.asm_b)); UP(upload(h, pl.asm_pidx, &dp.asm_pidx)); UP(upload(h, pl.blk_diag, &dp.blk_diag));
+  if (h->variant > 0) {
+    const ResPlan &rp = h->rplan; DevRes &dr = h->dres;
+    dr.nphase = rp.nphase; dr.ntemp = rp.ntemp;
+    UP(upload(h, rp.col_diag, &dr.col_diag)); UP(upload(h, rp.w_ptr, &dr.w_ptr)); UP(upload(h, rp.w_slot, &dr.w_slot));
+    UP(upload(h, rp.u_ptr, &dr.u_ptr)); UP(upload(h, rp.u_dst, &dr.u_dst)); UP(upload(h, rp.u_tmp, &dr.u_tmp)); UP(upload(h, rp.u_b, &dr.u_b));
+    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8;
+  }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
   dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.ws_stride = w.stride;
@@ -730,9 +1453,14 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   UP(dalloc(h, &h->ox, (size_t)batch * n)); UP(dalloc(h, &h->oy, (size_t)batch * std::max(m, 1))); UP(dalloc(h, &h->oz, (size_t)batch * std::max(m, 1)));
   UP(dalloc(h, &h->oinfo, (size_t)batch * 4)); UP(dalloc(h, &h->ocs, (size_t)batch));
   UP(dalloc(h, &h->ostatus, (size_t)batch)); UP(dalloc(h, &h->oiters, (size_t)batch));
+#ifdef MPCQP_TIMING
+  UP(dalloc(h, &h->odbg, (size_t)batch * 16 + 128));
+#endif
 #undef UP
   if (h->lds > 48 * 1024) {
-    if (hipFuncSetAttribute((const void *)mpcqp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
+    const void *fn = h->variant == 1 ? (const void *)mpcqp_res_kernel<1> : h->variant == 4 ? (const void *)mpcqp_res_kernel<4>
+                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8> : (const void *)mpcqp_admm_kernel;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
       return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
   }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
@@ -798,9 +1526,12 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   HIPCHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   DevIO io = h->io;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   HIPCHK(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(mpcqp_admm_kernel, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  if (h->variant == 1) hipLaunchKernelGGL(mpcqp_res_kernel<1>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 4) hipLaunchKernelGGL(mpcqp_res_kernel<4>, dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 8) hipLaunchKernelGGL(mpcqp_res_kernel<8>, dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else hipLaunchKernelGGL(mpcqp_admm_kernel, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
   h->last_stream = s; h->solved = true;
@@ -855,7 +1586,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
   o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
-  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = 0;
+  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->variant;
   return MPCQP_OK;
 }
 
@@ -872,6 +1603,17 @@ int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c)
   if (c) HIPCHK(hipMemcpy(c, h->ocs + b, sizeof(double), hipMemcpyDeviceToHost));
   return MPCQP_OK;
 }
+
+#ifdef MPCQP_TIMING
+// timing build only: per-QP cycle counts of the 16 instrumented segments (copied to host)
+int mpcqp_debug_timing(mpcqp_handle *h, long long *out) {
+  if (!h || !out || !h->odbg) return fail(MPCQP_ERR_ARG, "no timing data");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->last_stream));
+  HIPCHK(hipMemcpy(out, h->odbg, ((size_t)h->batch * 16 + 128) * sizeof(long long), hipMemcpyDeviceToHost));
+  return MPCQP_OK;
+}
+#endif
 
 int mpcqp_debug_blockops(const double *A, const double *B, const double *C, const double *S, double *out_gemm, double *out_linv, int *potrf_fail) {
   if (!A || !B || !C || !S || !out_gemm || !out_linv || !potrf_fail) return fail(MPCQP_ERR_ARG, "null pointer");

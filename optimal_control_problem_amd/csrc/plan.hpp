@@ -87,8 +87,40 @@ struct Plan {
   std::vector<int> asm_a, asm_b;     // T block ids
   std::vector<int> asm_pidx;         // [nblk*256], MFMA C layout [blk][g][lane] -> P ELL entry or -1
   std::vector<int> blk_diag;         // [nblk] J if diagonal block else -1
+  std::vector<std::vector<int>> colrows;  // [nb] off-diagonal block rows I > J of column J, ascending
   std::string error;
 };
+
+// ---- "resident" variant: block LDL' (M = W D W', D_J = S_JJ, G_J = D_J^-1, W_IJ = S_IJ G_J) held in LDS.
+// Solve: forward t_I -= W_IJ t_J, diagonal x_J = G_J t_J, backward x_J -= W_IJ' x_I -- a single copy of each
+// block serves both sweeps and the critical chain is one mat-vec per stage. Ops are scheduled into phases over
+// nw waves (barrier between phases unless both neighbours run entirely on one and the same wave).
+enum { SOP_SUB = 0, SOP_SUBT = 1, SOP_SET = 2 };
+inline int pack_sop(int kind, int slot, int src, int dst) { return kind | (slot << 2) | (src << 14) | (dst << 23); }
+struct ResPlan {
+  int nw = 1, ntemp = 0, nphase = 0;
+  // factorisation, per block column K
+  std::vector<int> col_diag;             // [nb]
+  std::vector<int> w_ptr, w_slot;        // W_IK = S_IK G_K -> temp tile (index within column)
+  std::vector<int> u_ptr, u_dst, u_tmp, u_b;  // S_IJ -= temp(I) * S_JK'
+  // solve schedule: ops of phase p, wave w are s_ops[s_ptr[p*nw+w] .. s_ptr[p*nw+w+1])
+  std::vector<int> s_ptr, s_ops, s_bar;  // s_bar[p] = 1 if a workgroup barrier must follow phase p
+  // the same schedule flattened per wave: op words with SOP_BAR markers where the workgroup synchronises;
+  // wave w executes l_ops[l_ptr[w] .. l_ptr[w+1]); the kernel copies this list into LDS once
+  std::vector<int> l_ptr, l_ops;
+  // and as 4-int records the kernel executes without decoding: {block byte offset, src byte offset in the
+  // vector, dst byte offset, flags}; r_ptr[w] .. r_ptr[w+1] in records
+  std::vector<int> r_ptr, r_rec;
+  // ... and compressed into segments: maximal runs of records whose block / src / dst offsets form an arithmetic
+  // progression and whose flags agree. 8 ints per segment {b0, s0, d0, flags, count, db, ds, dd};
+  // g_ptr[w] .. g_ptr[w+1] in segments. The kernel runs one tight induction-variable loop per segment.
+  std::vector<int> g_ptr, g_seg;
+};
+constexpr int SOP_BAR = 3;
+enum { RF_T = 1, RF_SET = 2, RF_FLUSH = 4, RF_BAR = 8, RF_NOP = 16, RF_PRE = 32 };
+// segment flags: SG_EACH = every op writes its own destination; otherwise the ops accumulate into one destination
+// which is written at the segment's end iff SG_END (a run split over several segments carries the partial sum on)
+enum { SG_T = 1, SG_SET = 2, SG_EACH = 4, SG_END = 8, SG_BAR = 16, SG_NOP = 32 };
 
 namespace detail {
 
@@ -239,6 +271,8 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
     for (int I : pat[J]) if (I != J) { bid[{I, J}] = (int)pl.blkI.size(); pl.blkI.push_back(I); pl.blkJ.push_back(J); }
   }
   pl.nblk = (int)pl.blkI.size();
+  pl.colrows.assign(pl.nb, {});
+  for (int J = 0; J < pl.nb; J++) for (int I : pat[J]) if (I != J) pl.colrows[J].push_back(I);
   pl.fwd_ops.resize(pl.nblk); pl.blk_diag.assign(pl.nblk, -1);
   for (int b = 0; b < pl.nblk; b++) {
     int I = pl.blkI[b], J = pl.blkJ[b];
@@ -314,6 +348,165 @@ inline WsLayout ws_layout(const Plan &pl) {
   w.stride = o;
   return w;
 }
+inline int block_id(const Plan &pl, int I, int J) {
+  for (int b = 0; b < pl.nblk; b++) if (pl.blkI[b] == I && pl.blkJ[b] == J) return b;
+  return -1;
+}
+
+inline ResPlan build_res_plan(const Plan &pl, int nw) {
+  ResPlan rp; rp.nw = nw;
+  const int nb = pl.nb;
+  std::map<std::pair<int, int>, int> bid;
+  for (int b = 0; b < pl.nblk; b++) bid[{pl.blkI[b], pl.blkJ[b]}] = b;
+  // ---- factor plan (right-looking)
+  rp.w_ptr.push_back(0); rp.u_ptr.push_back(0);
+  for (int K = 0; K < nb; K++) {
+    rp.col_diag.push_back(bid[{K, K}]);
+    const std::vector<int> &rows = pl.colrows[K];
+    rp.ntemp = std::max(rp.ntemp, (int)rows.size());
+    for (size_t a = 0; a < rows.size(); a++) rp.w_slot.push_back(bid[{rows[a], K}]);
+    rp.w_ptr.push_back((int)rp.w_slot.size());
+    for (size_t a = 0; a < rows.size(); a++) for (size_t b = 0; b <= a; b++) {
+      rp.u_dst.push_back(bid.at({rows[a], rows[b]})); rp.u_tmp.push_back((int)a); rp.u_b.push_back(bid[{rows[b], K}]);
+    }
+    rp.u_ptr.push_back((int)rp.u_dst.size());
+  }
+  // ---- solve schedule: backward ASAP levels at op granularity, forward = mirror image
+  std::vector<int> fin(nb, 0);
+  int maxlev = -1;
+  struct Op { int slot, I, J, lev; };
+  std::vector<Op> ops;
+  for (int J = nb - 1; J >= 0; J--) {
+    int f = 0;
+    for (int I : pl.colrows[J]) { ops.push_back({bid[{I, J}], I, J, fin[I]}); f = std::max(f, fin[I] + 1); maxlev = std::max(maxlev, fin[I]); }
+    fin[J] = pl.colrows[J].empty() ? 0 : f;
+  }
+  const int nlev = maxlev + 1;
+  // phases: forward nlev (levels descending), 1 diagonal, backward nlev (levels ascending)
+  auto distribute = [&](std::vector<std::vector<int>> groups) {   // groups of packed ops sharing a dst
+    std::vector<std::vector<int>> per(nw);
+    std::stable_sort(groups.begin(), groups.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a.size() > b.size(); });
+    for (auto &g : groups) {
+      int best = 0;
+      for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w;
+      per[best].insert(per[best].end(), g.begin(), g.end());
+    }
+    return per;
+  };
+  std::vector<std::vector<std::vector<int>>> phases;
+  for (int lev = nlev - 1; lev >= 0; lev--) {       // forward: t_I -= W_IJ t_J, grouped by dst I
+    std::map<int, std::vector<int>> g;
+    for (auto &o : ops) if (o.lev == lev) g[o.I].push_back(pack_sop(SOP_SUB, o.slot, o.J, o.I));
+    std::vector<std::vector<int>> gs; for (auto &kv : g) gs.push_back(kv.second);
+    phases.push_back(distribute(gs));
+  }
+  {
+    std::vector<std::vector<int>> gs;
+    for (int J = 0; J < nb; J++) gs.push_back({pack_sop(SOP_SET, bid[{J, J}], J, J)});
+    phases.push_back(distribute(gs));
+  }
+  for (int lev = 0; lev < nlev; lev++) {            // backward: x_J -= W_IJ' x_I, grouped by dst J
+    std::map<int, std::vector<int>> g;
+    for (auto &o : ops) if (o.lev == lev) g[o.J].push_back(pack_sop(SOP_SUBT, o.slot, o.I, o.J));
+    std::vector<std::vector<int>> gs; for (auto &kv : g) gs.push_back(kv.second);
+    phases.push_back(distribute(gs));
+  }
+  rp.nphase = (int)phases.size();
+  rp.s_ptr.push_back(0);
+  auto solo = [&](const std::vector<std::vector<int>> &ph) {  // wave that owns every op of the phase, or -1
+    int w0 = -1;
+    for (int w = 0; w < nw; w++) if (!ph[w].empty()) { if (w0 >= 0) return -1; w0 = w; }
+    return w0 < 0 ? 0 : w0;
+  };
+  for (int p = 0; p < rp.nphase; p++) {
+    for (int w = 0; w < nw; w++) { rp.s_ops.insert(rp.s_ops.end(), phases[p][w].begin(), phases[p][w].end()); rp.s_ptr.push_back((int)rp.s_ops.size()); }
+    int bar = 1;
+    if (p + 1 < rp.nphase) { int a = solo(phases[p]), b = solo(phases[p + 1]); if (a >= 0 && a == b) bar = 0; }
+    rp.s_bar.push_back(nw > 1 ? bar : 0);
+  }
+  rp.l_ptr.push_back(0);
+  for (int w = 0; w < nw; w++) {
+    for (int p = 0; p < rp.nphase; p++) {
+      for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) rp.l_ops.push_back(rp.s_ops[q]);
+      if (rp.s_bar[p]) rp.l_ops.push_back(SOP_BAR);
+    }
+    rp.l_ptr.push_back((int)rp.l_ops.size());
+  }
+  // records: runs (same dst, same kind, same phase) are flushed once; RF_PRE marks ops after whose vector read the
+  // next op's block / old-destination fetch may already be issued (next op writes another block, no barrier between)
+  rp.r_ptr.push_back(0);
+  for (int w = 0; w < nw; w++) {
+    struct R { int b, s, d, f, dstblk; };
+    std::vector<R> recs;
+    for (int p = 0; p < rp.nphase; p++) {
+      const int a = rp.s_ptr[p * nw + w], e = rp.s_ptr[p * nw + w + 1];
+      for (int q = a; q < e; q++) {
+        unsigned op = (unsigned)rp.s_ops[q]; int kind = op & 3, slot = (op >> 2) & 0xfff, src = (op >> 14) & 0x1ff, dst = op >> 23;
+        int f = (kind == SOP_SUBT ? RF_T : 0) | (kind == SOP_SET ? RF_SET : 0);
+        bool cont = false;
+        if (q + 1 < e && kind != SOP_SET) { unsigned nx = (unsigned)rp.s_ops[q + 1]; cont = (int)(nx & 3) == kind && (int)(nx >> 23) == dst; }
+        if (!cont) f |= RF_FLUSH;
+        recs.push_back({slot * BLK * 8, src * BS * 8, dst * BS * 8, f, dst});
+      }
+      if (rp.s_bar[p]) { if (a < e) recs.back().f |= RF_BAR; else recs.push_back({0, 0, 0, RF_NOP, -1}); }
+    }
+    for (size_t i = 0; i + 1 < recs.size(); i++) {
+      const R &c = recs[i], &n = recs[i + 1];
+      if ((c.f & (RF_NOP | RF_BAR)) || (n.f & RF_NOP)) continue;
+      if ((c.f & RF_FLUSH) && n.dstblk == c.dstblk) continue;
+      recs[i].f |= RF_PRE;
+    }
+    for (auto &r : recs) { rp.r_rec.push_back(r.b); rp.r_rec.push_back(r.s); rp.r_rec.push_back(r.d); rp.r_rec.push_back(r.f); }
+    rp.r_ptr.push_back((int)rp.r_rec.size() / 4);
+    // ---- segments
+    if (w == 0) rp.g_ptr.push_back(0);
+    size_t i = 0;
+    while (i < recs.size()) {
+      const R &c = recs[i];
+      if (c.f & RF_NOP) { int sg[8] = {0, 0, 0, SG_NOP, 0, 0, 0, 0}; rp.g_seg.insert(rp.g_seg.end(), sg, sg + 8); i++; continue; }
+      const int tflag = (c.f & RF_T ? SG_T : 0) | (c.f & RF_SET ? SG_SET : 0);
+      size_t e = i + 1;
+      int db = 0, ds = 0, dd = 0, flags;
+      if (c.f & RF_FLUSH) {                       // ops that each write their own destination
+        flags = tflag | SG_EACH;
+        if (!(c.f & RF_BAR)) {
+          while (e < recs.size()) {
+            const R &n = recs[e], &p = recs[e - 1];
+            if ((n.f & RF_NOP) || !(n.f & RF_FLUSH) || (n.f & (RF_T | RF_SET)) != (c.f & (RF_T | RF_SET))) break;
+            if (e == i + 1) { db = n.b - p.b; ds = n.s - p.s; dd = n.d - p.d; if (dd == 0) break; }
+            else if (n.b - p.b != db || n.s - p.s != ds || n.d - p.d != dd) break;
+            e++;
+            if (n.f & RF_BAR) break;
+          }
+        }
+        if (recs[e - 1].f & RF_BAR) flags |= SG_BAR;
+      } else {                                    // a run accumulating into one destination
+        flags = tflag;
+        while (e < recs.size()) {
+          const R &n = recs[e], &p = recs[e - 1];
+          if (e == i + 1) { db = n.b - p.b; ds = n.s - p.s; }
+          else if (n.b - p.b != db || n.s - p.s != ds) break;
+          e++;
+          if (n.f & RF_FLUSH) break;
+        }
+        if (recs[e - 1].f & RF_FLUSH) flags |= SG_END;
+        if (recs[e - 1].f & RF_BAR) flags |= SG_BAR;
+      }
+      int sg[8] = {c.b, c.s, c.d, flags, (int)(e - i), db, ds, dd};
+      rp.g_seg.insert(rp.g_seg.end(), sg, sg + 8);
+      i = e;
+    }
+    rp.g_ptr.push_back((int)rp.g_seg.size() / 8);
+  }
+  return rp;
+}
+
+// LDS footprint of the resident variant: blocks + temp tiles + x, q, r [npad] + z, y, w [mpad] + scratch
+inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
+  const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
+  return ((long)pl.nblk * BLK + (long)rp.ntemp * BLK + 3L * pl.npad + 3L * pl.mpad + 64 + 32L * rp.nw + sched_words) * 8L;
+}
+
 inline long lds_bytes(const Plan &pl) {
   // x, q, r [npad]; z, y, w [mpad]; two padded 16x17 scratch tiles; 64 doubles of reduction scratch
   return (3L * pl.npad + 3L * pl.mpad + 2L * BS * (BS + 1) + 64) * 8L;

@@ -138,3 +138,129 @@ int plan_execute(int n, int m, const int *Pp, const int *Pi, const int *Ap, cons
 }
 
 }  // extern "C"
+
+// symmetric sweep: in-place inverse of an SPD 16x16 block (what the resident kernel's wave does)
+static bool sweep_inverse(double *a) {
+  for (int k = 0; k < BS; k++) {
+    double row[BS];
+    for (int c = 0; c < BS; c++) row[c] = a[k * BS + c];
+    const double d = row[k];
+    if (!(d > 0)) return false;
+    const double p = 1.0 / d;
+    for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) {
+      const double colk = row[r];
+      if (r != k && c != k) a[r * BS + c] -= colk * row[c] * p;
+      else if (r == k && c != k) a[r * BS + c] = row[c] * p;
+      else if (r != k && c == k) a[r * BS + c] = colk * p;
+      else a[r * BS + c] = -p;
+    }
+  }
+  for (int i = 0; i < BLK; i++) a[i] = -a[i];
+  return true;
+}
+
+extern "C" {
+
+// Resident-variant plan: block LDL' factor plan + phase schedule over nw waves, executed serially with race checks.
+// returns 0 ok, 1 plan error, 2 not positive definite, 3 schedule hazard (two waves touch one vector block in a phase)
+int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw,
+                     const double *Pval, const double *Aval, const double *rho, double sigma,
+                     const double *rhs, double *sol, long *info) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, -1);
+  if (!pl.error.empty()) return 1;
+  ResPlan rp = build_res_plan(pl, nw);
+  if (info) { info[0] = rp.ntemp; info[1] = rp.nphase; info[2] = lds_bytes_res(pl, rp); int nb = 0; for (int b : rp.s_bar) nb += b; info[3] = nb; }
+  // the segment compression must expand back to exactly the record list (offsets, kinds, flush and barrier points)
+  for (int w = 0; w < nw; w++) {
+    std::vector<int> ex;   // expanded {b, s, d, T|SET, flush, bar} per op; barriers-only as {-1,...}
+    bool open_run = false;
+    for (int g = rp.g_ptr[w]; g < rp.g_ptr[w + 1]; g++) {
+      const int *sg = &rp.g_seg[8 * g];
+      if (sg[3] & SG_NOP) { ex.insert(ex.end(), {-1, 0, 0, 0, 0, 1}); continue; }
+      for (int k = 0; k < sg[4]; k++) {
+        const bool last = k + 1 == sg[4];
+        const int flush = (sg[3] & SG_EACH) ? 1 : (last && (sg[3] & SG_END) ? 1 : 0);
+        ex.insert(ex.end(), {sg[0] + k * sg[5], sg[1] + k * sg[6], sg[2] + ((sg[3] & SG_EACH) ? k * sg[7] : 0), sg[3] & (SG_T | SG_SET), flush, last && (sg[3] & SG_BAR) ? 1 : 0});
+        open_run = !flush;
+      }
+    }
+    if (open_run) return 4;
+    size_t e = 0;
+    for (int q = rp.r_ptr[w]; q < rp.r_ptr[w + 1]; q++, e += 6) {
+      const int *rc = &rp.r_rec[4 * q];
+      if (e + 6 > ex.size()) return 4;
+      if (rc[3] & RF_NOP) { if (ex[e] != -1) return 4; continue; }
+      const int tf = ((rc[3] & RF_T) ? SG_T : 0) | ((rc[3] & RF_SET) ? SG_SET : 0);
+      if (ex[e] != rc[0] || ex[e + 1] != rc[1] || ex[e + 2] != rc[2] || ex[e + 3] != tf || ex[e + 4] != ((rc[3] & RF_FLUSH) ? 1 : 0) ||
+          ex[e + 5] != ((rc[3] & RF_BAR) ? 1 : 0)) return 4;
+    }
+    if (e != ex.size()) return 4;
+  }
+  if (info) info[3] = (long)rp.g_seg.size() / 8 * 1000 + info[3];   // segments * 1000 + barriers
+  std::vector<double> vA, vAt, vP;
+  ell_fill(pl.A, Aval, vA); ell_fill(pl.At, Aval, vAt); ell_fill(pl.P, Pval, vP);
+  std::vector<double> dvec(pl.npad, 1.0);
+  for (int c = 0; c < pl.At.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int t = c * WAVE + lane; if (t >= pl.npad) continue;
+    double a = 0;
+    for (int s = pl.At.chunk_off[c]; s < pl.At.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.At.flag[p]) a += rho[pl.At.idx[p]] * vAt[p] * vAt[p]; }
+    dvec[t] = pl.perm[t] >= 0 ? sigma + a : 1.0;
+  }
+  std::vector<double> T((size_t)std::max(pl.nT, 1) * BLK, 0.0);
+  for (int c = 0; c < pl.A.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int i = c * WAVE + lane; if (i >= m) continue;
+    for (int s = pl.A.chunk_off[c]; s < pl.A.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.tpos[p] >= 0) T[pl.tpos[p]] = vA[p] * std::sqrt(rho[i]); }
+  }
+  std::vector<double> S((size_t)pl.nblk * BLK, 0.0), tmp((size_t)std::max(rp.ntemp, 1) * BLK, 0.0);
+  for (int b = 0; b < pl.nblk; b++) {
+    double *C = &S[(size_t)b * BLK];
+    for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) gemm_abt(&T[(size_t)pl.asm_a[g] * BLK], &T[(size_t)pl.asm_b[g] * BLK], C, 1.0);
+    for (int g = 0; g < 4; g++) for (int lane = 0; lane < WAVE; lane++) {
+      int row = (lane >> 4) + 4 * g, col = lane & 15;
+      int pi = pl.asm_pidx[(size_t)b * BLK + g * WAVE + lane];
+      if (pi >= 0) C[row * BS + col] += vP[pi];
+      if (pl.blk_diag[b] >= 0 && row == col) C[row * BS + col] += dvec[pl.blk_diag[b] * BS + row];
+    }
+  }
+  for (int K = 0; K < pl.nb; K++) {
+    double *G = &S[(size_t)rp.col_diag[K] * BLK];
+    if (!sweep_inverse(G)) return 2;
+    int nwk = rp.w_ptr[K + 1] - rp.w_ptr[K];
+    for (int a = 0; a < nwk; a++) {
+      double *t = &tmp[(size_t)a * BLK];
+      std::memset(t, 0, BLK * sizeof(double));
+      gemm_abt(&S[(size_t)rp.w_slot[rp.w_ptr[K] + a] * BLK], G, t, 1.0);   // W = S G  (G symmetric)
+    }
+    for (int u = rp.u_ptr[K]; u < rp.u_ptr[K + 1]; u++) gemm_abt(&tmp[(size_t)rp.u_tmp[u] * BLK], &S[(size_t)rp.u_b[u] * BLK], &S[(size_t)rp.u_dst[u] * BLK], -1.0);
+    for (int a = 0; a < nwk; a++) std::memcpy(&S[(size_t)rp.w_slot[rp.w_ptr[K] + a] * BLK], &tmp[(size_t)a * BLK], BLK * sizeof(double));
+  }
+  std::vector<double> v(pl.npad, 0.0);
+  for (int j = 0; j < n; j++) v[pl.pos[j]] = rhs[j];
+  int last_solo = -2;
+  for (int p = 0; p < rp.nphase; p++) {
+    std::vector<int> writer(pl.nb, -1), reader(pl.nb, -1);
+    int owner = -1, nown = 0;
+    for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
+      unsigned op = (unsigned)rp.s_ops[q]; int src = (op >> 14) & 0x1ff, dst = op >> 23;
+      if (writer[dst] >= 0 && writer[dst] != w) return 3;
+      writer[dst] = w;
+      if (reader[src] < 0) reader[src] = w; else if (reader[src] != w) reader[src] = nw;   // several readers are fine
+      if (owner != w) { owner = w; nown++; }
+    }
+    for (int b = 0; b < pl.nb; b++) if (writer[b] >= 0 && reader[b] >= 0 && reader[b] != writer[b]) return 3;
+    // a phase that follows a barrier-less boundary must run on the same single wave as its predecessor
+    if (p > 0 && !rp.s_bar[p - 1] && nw > 1 && !(nown <= 1 && (nown == 0 || owner == last_solo))) return 3;
+    last_solo = nown == 1 ? owner : (nown == 0 ? last_solo : -1);
+    for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
+      unsigned op = (unsigned)rp.s_ops[q]; int kind = op & 3, slot = (op >> 2) & 0xfff, src = (op >> 14) & 0x1ff, dst = op >> 23;
+      const double *B = &S[(size_t)slot * BLK];
+      double out[BS];
+      for (int r = 0; r < BS; r++) { double a = 0; for (int c = 0; c < BS; c++) a += (kind == SOP_SUBT ? B[c * BS + r] : B[r * BS + c]) * v[src * BS + c]; out[r] = a; }
+      for (int r = 0; r < BS; r++) v[dst * BS + r] = kind == SOP_SET ? out[r] : v[dst * BS + r] - out[r];
+    }
+  }
+  for (int j = 0; j < n; j++) sol[j] = v[pl.pos[j]];
+  return 0;
+}
+
+}  // extern "C"

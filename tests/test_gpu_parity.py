@@ -274,3 +274,46 @@ def test_full_size_quadrotor_properties(built):
     ref = problems.oracle_solve(sub)
     assert (ref["iters"] == got["iters"][sl]).all()
     assert np.abs(ref["x"] - got["x"][sl]).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- kernel variants
+@pytest.mark.parametrize("variant", ["stream", "res1", "res4", "res8"])
+@pytest.mark.parametrize("name,batch,N", [("double_integrator", 40, 20), ("quadrotor", 24, 20), ("cartpole", 6, 30)])
+def test_kernel_variants_vs_oracle(built, monkeypatch, variant, name, batch, N):
+    """every kernel family (HBM-streamed factor; LDS-resident block LDL' with 1 / 4 / 8 waves per QP) against the oracle"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", variant)
+    mdl, ls, _ = models.make_workload(name, batch, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert qp.plan_info()["variant"] == {"stream": 0, "res1": 1, "res4": 4, "res8": 8}[variant]
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+
+
+@pytest.mark.parametrize("variant", ["stream", "res1", "res4"])
+def test_kernel_variants_hard_cases(built, monkeypatch, variant):
+    """adaptive-rho refactorisation, infeasibility certificates, max-iter exit, non-convex rejection per kernel family"""
+    monkeypatch.setenv("MPCQP_VARIANT", variant)
+    for seed in range(6):
+        _compare(problems.random_qp(11 + 3 * seed, 17 + 5 * seed, seed))
+    assert _compare(problems.random_qp(12, 20, 101, infeasible="primal"))[0]["status"][0] == 3
+    assert _compare(problems.random_qp(12, 20, 102, infeasible="dual"))[0]["status"][0] == 5
+    ls = problems.random_qp(14, 22, 7)
+    _compare(ls, scaling=0); _compare(ls, max_iter=20, adaptive_rho=0); _compare(ls, adaptive_rho_interval=25, eps_abs=1e-6, eps_rel=1e-6)
+    from optimal_control_problem_amd.batch_qp import solve_local_system
+    mdl, arg, _ = models.reference_test_cases()[7]
+    assert solve_local_system(problems.toy_local_system(mdl, arg))["status"][0] == 9
+    mdl, ls, _ = models.make_workload("double_integrator", 8)
+    cold = problems.oracle_solve(ls)
+    from oracle import oracle as orc
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    ref = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings(warm_start=1), x0=cold["x"], y0=cold["y"])
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, warm_start=1)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.warm_start(cold["x"], cold["y"]); qp.solve()
+    got = qp.get(); qp.close()
+    assert (got["iters"] == ref["iters"]).all()
+    _close(got, ref, "x")

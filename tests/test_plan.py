@@ -67,3 +67,53 @@ def test_plan_no_constraints_rows_only_boxes(built):
     mdl, arg, _ = models.reference_test_cases()[1]    # no g rows: A is the identity
     info = _run(problems.toy_local_system(mdl, arg))
     assert info["nT"] == 0
+
+
+# ---- resident variant: block LDL' factor plan + phase schedule over nw waves (race-checked by the interpreter)
+def _run_res(ls, nw, b=0, seed=0):
+    L = C.CDLL(SO)
+    rng = np.random.default_rng(seed)
+    n, m = ls.n, ls.m
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(4, np.int64)
+    Pv = np.ascontiguousarray(ls.P[b]); Av = np.ascontiguousarray(ls.A[b])
+    rc = L.plan_execute_res(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), nw, _p(Pv), _p(Av), _p(rho), C.c_double(sigma),
+                            _p(rhs), _p(sol), _p(info))
+    assert rc == 0, rc
+    ref = np.linalg.solve(M, rhs)
+    assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
+    return dict(ntemp=info[0], nphase=info[1], lds=info[2], barriers=info[3] % 1000, segments=info[3] // 1000)
+
+
+@pytest.mark.parametrize("nw", [1, 4, 8])
+@pytest.mark.parametrize("name,N", [("double_integrator", 20), ("quadrotor", 20), ("cartpole", 30)])
+def test_res_plan_stage_models(built, name, N, nw):
+    mdl, ls, _ = models.make_workload(name, 1, N=N)
+    info = _run_res(ls, nw)
+    assert info["ntemp"] == 2                                   # next-stage block + parameter (arrow) block per column
+    if nw > 1:
+        assert info["barriers"] == 4                            # arrow phase, diagonal phase, and the two chain ends
+    if name == "quadrotor":
+        assert info["nphase"] == 41 and info["lds"] < 160 * 1024
+        # 100 block ops compress into a handful of arithmetic-progression segments per wave
+        assert info["segments"] <= 6 * nw + 4
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_res_plan_random(built, seed):
+    ls = problems.random_qp(20 + 13 * seed, 30 + 11 * seed, seed, density=0.15)
+    for nw in (1, 4):
+        _run_res(ls, nw, seed=seed)
+
+
+def test_res_plan_rejects_indefinite(built):
+    mdl, arg, _ = models.reference_test_cases()[7]
+    ls = problems.toy_local_system(mdl, arg)
+    L = C.CDLL(SO)
+    rho = np.full(ls.m, 0.1); rhs = np.ones(ls.n); sol = np.zeros(ls.n); info = np.zeros(4, np.int64)
+    Pv = np.ascontiguousarray(ls.P[0]); Av = np.ascontiguousarray(ls.A[0])
+    assert L.plan_execute_res(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), 1, _p(Pv), _p(Av), _p(rho), C.c_double(1e-6),
+                              _p(rhs), _p(sol), _p(info)) == 2

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-segment cycle breakdown of the resident kernel (needs libmpcqp_timing.so, see csrc/Makefile).
+usage: MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py [workload] [batch] [variant]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+name = sys.argv[1] if len(sys.argv) > 1 else "quadrotor"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+if len(sys.argv) > 3:
+    os.environ["MPCQP_VARIANT"] = sys.argv[3]
+from optimal_control_problem_amd import _lib, models
+from optimal_control_problem_amd.batch_qp import BatchQP
+
+mdl, ls, _ = models.make_workload(name, batch)
+qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+qp.update(ls.P, ls.q, ls.A, ls.l, ls.u)
+for _ in range(2):
+    qp.solve(); got = qp.get()
+ms = qp.last_kernel_ms()
+raw = np.zeros(batch * 16 + 128, np.int64); out = raw[:batch * 16].reshape(batch, 16)
+L = _lib.lib()
+L.mpcqp_debug_timing.argtypes = [C.c_void_p, C.c_void_p]
+_lib.check(L.mpcqp_debug_timing(qp._h, raw.ctypes.data))
+names = ["load", "ruiz", "apply-scale+init", "factor(first)", "At pass", "schedule(solve)", "A pass + x", "check", "store",
+         "-", "-", "-", "f:rho/dvec/T", "f:assemble", "f:LDL", "-"]
+tot = out[:, :9].sum(axis=1).mean()
+print("variant", qp.plan_info()["variant"], "kernel %.2f ms for %d QPs, mean iters %.1f, mean cycles/QP %.0f (100 MHz ticks: %s)" % (
+    ms, batch, got["iters"].mean(), tot, "s_memtime"))
+for k, nm in enumerate(names):
+    if nm != "-":
+        print("  %-20s %10.0f cyc  %5.1f %%" % (nm, out[:, k].mean(), 100 * out[:, k].mean() / tot))
+it = got["iters"].mean()
+print("  per ADMM iteration: At %.0f, solve %.0f, A+x %.0f cycles" % (out[:, 4].mean() / it, out[:, 5].mean() / it, out[:, 6].mean() / it))
+
+tr = raw[batch * 16:]
+if tr[0] > 0:
+    d = np.diff(tr[:122]); d = d[(d > 0) & (d < 10**7)]
+    print("  wave-0 record trace of one solve (cycles per record, %d records):" % len(d))
+    print("   ", d.tolist())
