@@ -613,7 +613,7 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
 struct DevRes {
   int nphase, ntemp;
   const int *col_diag, *w_ptr, *w_slot, *u_ptr, *u_dst, *u_tmp, *u_b, *g_ptr, *g_seg;
-  int n_seg;
+  int n_seg; long stage;
 };
 
 template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
@@ -646,6 +646,8 @@ __device__ __forceinline__ void block_combine(double (&v)[K], double *red, int w
   }
 }
 
+// ELL sweeps for the multi-wave kernels: wave `wid` takes chunks wid, wid + NW, ... (A 16-deep clamped full unroll
+// and a 4-lanes-per-row split were both measured slower on MI355X: spills / more latency rounds; see DESIGN.md.)
 template <int NW, class F>
 __device__ __forceinline__ void ell_rows_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
   for (int c = wid; c < E.nchunks; c += NW) {
@@ -683,53 +685,6 @@ __device__ __forceinline__ double quad_sum(double v) {
   t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
   t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true);
   return a.d + t.d;
-}
-
-__device__ __forceinline__ double quad_max(double v) {
-  union { double d; int i[2]; } a, t;
-  a.d = v;
-  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true);
-  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true);
-  a.d = fmax(a.d, t.d);
-  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true);
-  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true);
-  return fmax(a.d, t.d);
-}
-
-// ELL sweeps with 4 lanes per row: a wave covers 16 rows per step, lane group g takes slots s0+g, s0+g+4, ...;
-// every load of a row is in flight at once (one L2 round trip per step) and the row sum is a quad DPP reduction.
-// f(row, value) runs on the g == 0 lane of each row only.
-template <int NW, class F>
-__device__ __forceinline__ void ell_rows_q(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  const int rr = lane >> 2, g = lane & 3;
-  for (int st = wid; st < 4 * E.nchunks; st += NW) {
-    const int c = st >> 2, row = (st & 3) * 16 + rr;
-    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
-    double acc = 0.0;
-#pragma unroll 4
-    for (int s = s0 + g; s < s1; s += 4) {
-      const long e = (long)s * WAVE + row;
-      acc += val[e] * in[E.idx[e]];
-    }
-    acc = quad_sum(acc);
-    if (g == 0) f(c * WAVE + row, acc);
-  }
-}
-template <int NW, class F>
-__device__ __forceinline__ void ell_rowmax_q(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  const int rr = lane >> 2, g = lane & 3;
-  for (int st = wid; st < 4 * E.nchunks; st += NW) {
-    const int c = st >> 2, row = (st & 3) * 16 + rr;
-    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
-    double acc = 0.0;
-#pragma unroll 4
-    for (int s = s0 + g; s < s1; s += 4) {
-      const long e = (long)s * WAVE + row;
-      acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
-    }
-    acc = quad_max(acc);
-    if (g == 0) f(c * WAVE + row, acc);
-  }
 }
 
 // acc += A * B^T, operands row-major 16x16 tiles (LDS or global), lane = lane within the wave
@@ -1111,7 +1066,7 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
   cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
   cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK;
-  cx.X = cx.TMP + (long)rs.ntemp * BLK; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
+  cx.X = cx.BL + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
   cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 64;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
@@ -1127,9 +1082,13 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   TS_DECL;
   for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
   if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
-  for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; valA[e] = s >= 0 ? inA[s] : 0.0; }
-  for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; valAt[e] = s >= 0 ? inA[s] : 0.0; }
-  for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; valP[e] = s >= 0 ? inP[s] : 0.0; }
+  // ---- load: caller's CSC values -> ELL arrays. The block region of LDS is idle until the factorisation, so the
+  // ELL values of A, A', P live there for the whole scaling phase (host guarantees they fit) and are written to
+  // the HBM slab once, already scaled.
+  double *sA = cx.BL, *sAt = sA + pl.A.entries, *sP = sAt + pl.At.entries;
+  for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }
+  for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
   for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
   for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
   bsync<NW>();
@@ -1144,17 +1103,17 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
       const int t = ch * WAVE + lane;
       double nA = 0.0, nP = 0.0;
 #pragma unroll 8
-      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nA = fmax(nA, fabs(valAt[e]) * cx.W[pl.At.idx[e]]); }
-      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nP = fmax(nP, fabs(valP[e]) * cx.R[pl.P.idx[e]]); }
+      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nA = fmax(nA, fabs(sAt[e]) * cx.W[pl.At.idx[e]]); }
+      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nP = fmax(nP, fabs(sP[e]) * cx.R[pl.P.idx[e]]); }
       if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
     }
-    ell_rowmax_w<NW>(pl.A, valA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+    ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
     bsync<NW>();
     for (int t = tid; t < npad; t += NT) cx.R[t] *= cx.X[t];
     for (int i = tid; i < mpad; i += NT) cx.W[i] *= cx.Z[i];
     bsync<NW>();
     double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
-    ell_rowmax_w<NW>(pl.P, valP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+    ell_rowmax_w<NW>(pl.P, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
     block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
     const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
     c *= ct;
@@ -1162,14 +1121,15 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   }
   cx.c = c; cx.cinv = 1.0 / c;
   TS(1);
+  // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
   for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
     const int i = ch * WAVE + lane; const double ei = cx.W[i];
-    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] *= ei * cx.R[pl.A.idx[e]]; }
+    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
   }
   for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
     const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
-    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] *= dj * cx.W[pl.At.idx[e]]; }
-    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] *= c * dj * cx.R[pl.P.idx[e]]; }
+    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
+    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
   }
   bsync<NW>();
   for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
@@ -1415,6 +1375,11 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       if (small_ok && lds_bytes_res(pl, r1) <= 40 * 1024) want = 1;
       else { ResPlan r4 = build_res_plan(pl, 4); want = (small_ok && lds_bytes_res(pl, r4) <= LDS_MAX) ? 4 : 0; }
     }
+    if (want >= 2 && !getenv("MPCQP_NO_TWIST")) {
+      // multi-wave resident kernels: eliminate the stage chain from both ends (two concurrent half-length chains)
+      Plan tw = build_plan(n, m, Pp, Pi, Ap, Ai, 2);
+      if (tw.error.empty() && tw.ordering == 2 && tw.nblk <= h->plan.nblk) { h->plan = tw; h->wl = ws_layout(h->plan); }
+    }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want);
       const long need = lds_bytes_res(pl, h->rplan);
@@ -1444,7 +1409,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     dr.nphase = rp.nphase; dr.ntemp = rp.ntemp;
     UP(upload(h, rp.col_diag, &dr.col_diag)); UP(upload(h, rp.w_ptr, &dr.w_ptr)); UP(upload(h, rp.w_slot, &dr.w_slot));
     UP(upload(h, rp.u_ptr, &dr.u_ptr)); UP(upload(h, rp.u_dst, &dr.u_dst)); UP(upload(h, rp.u_tmp, &dr.u_tmp)); UP(upload(h, rp.u_b, &dr.u_b));
-    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8;
+    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = res_stage_doubles(pl, rp);
   }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;

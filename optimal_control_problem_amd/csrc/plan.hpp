@@ -220,8 +220,39 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
   int c_nat = eval(pos_nat, nullptr), c_hub = eval_gap(pos_hub, npad_hub, nullptr);
   bool use_hub = c_hub < c_nat;
   if (force_ordering == 0) use_hub = false;
-  if (force_ordering == 1) use_hub = true;
-  pl.ordering = use_hub ? 1 : 0;
+  if (force_ordering >= 1) use_hub = true;
+  // ordering 2 ("twisted"): when the non-hub blocks form a path (block tridiagonal), interleave them from both ends
+  // [0, k-1, 1, k-2, ...]: the elimination tree becomes two chains that meet in the middle -- same block count, half
+  // the sequential depth (two waves eliminate / substitute concurrently).
+  bool twisted = false;
+  if (force_ordering == 2) {
+    int nonhub = 0;   // hubs sit behind all non-hubs; count the leading variables that kept relative order 0..r-1
+    {
+      std::vector<int> inv(n, -1);
+      for (int v = 0; v < n; v++) inv[pos_hub[v]] = v;
+      // non-hubs are those whose successor in position order has a larger variable index (monotone prefix)
+      nonhub = n;
+      for (int t = 1; t < n; t++) if (inv[t] < inv[t - 1]) { nonhub = t; break; }
+    }
+    const int k = nonhub / BS;
+    if (nonhub % BS == 0 && k >= 4) {
+      std::vector<std::set<int>> badj(k);
+      bool path = true;
+      for (int v = 0; v < n && path; v++) if (pos_hub[v] < nonhub) for (int w : adj[v]) if (pos_hub[w] < nonhub) {
+        const int a = pos_hub[v] / BS, b = pos_hub[w] / BS;
+        if (std::abs(a - b) > 1) { path = false; break; }
+      }
+      if (path) {
+        std::vector<int> pos_tw(pos_hub);
+        for (int v = 0; v < n; v++) if (pos_hub[v] < nonhub) {
+          const int b = pos_hub[v] / BS, nbk = b < (k + 1) / 2 ? 2 * b : 2 * (k - 1 - b) + 1;
+          pos_tw[v] = nbk * BS + pos_hub[v] % BS;
+        }
+        if (eval_gap(pos_tw, npad_hub, nullptr) <= c_hub) { pos_hub = pos_tw; twisted = true; }
+      }
+    }
+  }
+  pl.ordering = use_hub ? (twisted ? 2 : 1) : 0;
   pl.pos = use_hub ? pos_hub : pos_nat;
   pl.npad = use_hub ? npad_hub : npad_nat;
   pl.nb = pl.npad / BS;
@@ -382,48 +413,68 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
     fin[J] = pl.colrows[J].empty() ? 0 : f;
   }
   const int nlev = maxlev + 1;
-  // phases: forward nlev (levels descending), 1 diagonal, backward nlev (levels ascending)
-  auto distribute = [&](std::vector<std::vector<int>> groups) {   // groups of packed ops sharing a dst
-    std::vector<std::vector<int>> per(nw);
-    std::stable_sort(groups.begin(), groups.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a.size() > b.size(); });
+  // phases: forward nlev (levels descending), 1 diagonal, backward nlev (levels ascending).
+  // Wave assignment: ops sharing a destination stay on one wave (register accumulation, no write races); a
+  // single-op group follows the wave that produced its source block ("affinity") so that independent chains stay on
+  // their own waves without synchronisation; everything else goes to the least-loaded wave.
+  struct SOp { int word, src, dst; };
+  std::vector<int> owner(nb, -1);
+  auto distribute = [&](std::vector<std::vector<SOp>> groups) {
+    std::vector<std::vector<SOp>> per(nw);
+    std::stable_sort(groups.begin(), groups.end(), [](const std::vector<SOp> &a, const std::vector<SOp> &b) { return a.size() > b.size(); });
+    const bool few = (int)groups.size() <= nw;
+    std::vector<char> taken(nw, 0);
     for (auto &g : groups) {
-      int best = 0;
-      for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w;
+      int best = -1;
+      if (few && g.size() == 1 && owner[g[0].src] >= 0 && !taken[owner[g[0].src]]) best = owner[g[0].src];
+      if (best < 0) {
+        best = 0;
+        for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w;
+        if (few && taken[best]) for (int w = 0; w < nw; w++) if (!taken[w]) { best = w; break; }
+      }
+      taken[best] = 1;
       per[best].insert(per[best].end(), g.begin(), g.end());
+      owner[g[0].dst] = best;
     }
     return per;
   };
-  std::vector<std::vector<std::vector<int>>> phases;
+  std::vector<std::vector<std::vector<SOp>>> phases;
   for (int lev = nlev - 1; lev >= 0; lev--) {       // forward: t_I -= W_IJ t_J, grouped by dst I
-    std::map<int, std::vector<int>> g;
-    for (auto &o : ops) if (o.lev == lev) g[o.I].push_back(pack_sop(SOP_SUB, o.slot, o.J, o.I));
-    std::vector<std::vector<int>> gs; for (auto &kv : g) gs.push_back(kv.second);
+    std::map<int, std::vector<SOp>> g;
+    for (auto &o : ops) if (o.lev == lev) g[o.I].push_back({pack_sop(SOP_SUB, o.slot, o.J, o.I), o.J, o.I});
+    std::vector<std::vector<SOp>> gs; for (auto &kv : g) gs.push_back(kv.second);
     phases.push_back(distribute(gs));
   }
   {
-    std::vector<std::vector<int>> gs;
-    for (int J = 0; J < nb; J++) gs.push_back({pack_sop(SOP_SET, bid[{J, J}], J, J)});
+    std::vector<std::vector<SOp>> gs;
+    for (int J = 0; J < nb; J++) gs.push_back({{pack_sop(SOP_SET, bid[{J, J}], J, J), J, J}});
+    std::fill(owner.begin(), owner.end(), -1);
     phases.push_back(distribute(gs));
   }
+  std::fill(owner.begin(), owner.end(), -1);
   for (int lev = 0; lev < nlev; lev++) {            // backward: x_J -= W_IJ' x_I, grouped by dst J
-    std::map<int, std::vector<int>> g;
-    for (auto &o : ops) if (o.lev == lev) g[o.J].push_back(pack_sop(SOP_SUBT, o.slot, o.I, o.J));
-    std::vector<std::vector<int>> gs; for (auto &kv : g) gs.push_back(kv.second);
+    std::map<int, std::vector<SOp>> g;
+    for (auto &o : ops) if (o.lev == lev) g[o.J].push_back({pack_sop(SOP_SUBT, o.slot, o.I, o.J), o.I, o.J});
+    std::vector<std::vector<SOp>> gs; for (auto &kv : g) gs.push_back(kv.second);
     phases.push_back(distribute(gs));
   }
   rp.nphase = (int)phases.size();
   rp.s_ptr.push_back(0);
-  auto solo = [&](const std::vector<std::vector<int>> &ph) {  // wave that owns every op of the phase, or -1
-    int w0 = -1;
-    for (int w = 0; w < nw; w++) if (!ph[w].empty()) { if (w0 >= 0) return -1; w0 = w; }
-    return w0 < 0 ? 0 : w0;
-  };
+  // a workgroup barrier is needed before a phase iff one of its ops touches a vector block that another wave has
+  // written (RAW / WAW) or read-then-it-writes (WAR) since the last barrier
+  std::vector<int> wby(nb, -1), rby(nb, 0);
+  rp.s_bar.assign(rp.nphase, 0);
   for (int p = 0; p < rp.nphase; p++) {
-    for (int w = 0; w < nw; w++) { rp.s_ops.insert(rp.s_ops.end(), phases[p][w].begin(), phases[p][w].end()); rp.s_ptr.push_back((int)rp.s_ops.size()); }
-    int bar = 1;
-    if (p + 1 < rp.nphase) { int a = solo(phases[p]), b = solo(phases[p + 1]); if (a >= 0 && a == b) bar = 0; }
-    rp.s_bar.push_back(nw > 1 ? bar : 0);
+    bool conflict = false;
+    for (int w = 0; w < nw && !conflict; w++) for (auto &o : phases[p][w]) {
+      if ((wby[o.src] >= 0 && wby[o.src] != w) || (wby[o.dst] >= 0 && wby[o.dst] != w) || (rby[o.dst] & ~(1 << w))) { conflict = true; break; }
+    }
+    if (conflict && p > 0) { rp.s_bar[p - 1] = 1; std::fill(wby.begin(), wby.end(), -1); std::fill(rby.begin(), rby.end(), 0); }
+    for (int w = 0; w < nw; w++) for (auto &o : phases[p][w]) { wby[o.dst] = w; rby[o.src] |= 1 << w; rby[o.dst] |= 1 << w; }
+    for (int w = 0; w < nw; w++) { for (auto &o : phases[p][w]) rp.s_ops.push_back(o.word); rp.s_ptr.push_back((int)rp.s_ops.size()); }
   }
+  rp.s_bar[rp.nphase - 1] = 1;
+  if (nw == 1) std::fill(rp.s_bar.begin(), rp.s_bar.end(), 0);
   rp.l_ptr.push_back(0);
   for (int w = 0; w < nw; w++) {
     for (int p = 0; p < rp.nphase; p++) {
@@ -502,9 +553,15 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
 }
 
 // LDS footprint of the resident variant: blocks + temp tiles + x, q, r [npad] + z, y, w [mpad] + scratch
+// doubles of the LDS region that holds the factor blocks + temp tiles during the solve and, before the first
+// factorisation, the staged ELL values of A, A', P
+inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
+  const long blocks = ((long)pl.nblk + rp.ntemp) * BLK, ell = pl.A.entries() + pl.At.entries() + pl.P.entries();
+  return (std::max(blocks, ell) + 15) / 16 * 16;
+}
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
-  return ((long)pl.nblk * BLK + (long)rp.ntemp * BLK + 3L * pl.npad + 3L * pl.mpad + 64 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles(pl, rp) + 3L * pl.npad + 3L * pl.mpad + 64 + 32L * rp.nw + sched_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {

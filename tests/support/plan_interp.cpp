@@ -166,10 +166,12 @@ extern "C" {
 int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw,
                      const double *Pval, const double *Aval, const double *rho, double sigma,
                      const double *rhs, double *sol, long *info) {
-  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, -1);
+  const int force = nw >= 100 ? nw / 100 : -1;
+  nw %= 100;
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force);
   if (!pl.error.empty()) return 1;
   ResPlan rp = build_res_plan(pl, nw);
-  if (info) { info[0] = rp.ntemp; info[1] = rp.nphase; info[2] = lds_bytes_res(pl, rp); int nb = 0; for (int b : rp.s_bar) nb += b; info[3] = nb; }
+  if (info) { info[0] = rp.ntemp + 100 * pl.ordering; info[1] = rp.nphase; info[2] = lds_bytes_res(pl, rp); int nb = 0; for (int b : rp.s_bar) nb += b; info[3] = nb; }
   // the segment compression must expand back to exactly the record list (offsets, kinds, flush and barrier points)
   for (int w = 0; w < nw; w++) {
     std::vector<int> ex;   // expanded {b, s, d, T|SET, flush, bar} per op; barriers-only as {-1,...}
@@ -236,21 +238,21 @@ int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, 
   }
   std::vector<double> v(pl.npad, 0.0);
   for (int j = 0; j < n; j++) v[pl.pos[j]] = rhs[j];
-  int last_solo = -2;
-  for (int p = 0; p < rp.nphase; p++) {
-    std::vector<int> writer(pl.nb, -1), reader(pl.nb, -1);
-    int owner = -1, nown = 0;
-    for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
-      unsigned op = (unsigned)rp.s_ops[q]; int src = (op >> 14) & 0x1ff, dst = op >> 23;
-      if (writer[dst] >= 0 && writer[dst] != w) return 3;
-      writer[dst] = w;
-      if (reader[src] < 0) reader[src] = w; else if (reader[src] != w) reader[src] = nw;   // several readers are fine
-      if (owner != w) { owner = w; nown++; }
+  // hazard check, independent of the scheduler: since the last workgroup barrier no wave may read or overwrite a
+  // vector block another wave has written, nor overwrite one another wave has read
+  {
+    std::vector<int> wby(pl.nb, -1), rby(pl.nb, 0);
+    for (int p = 0; p < rp.nphase; p++) {
+      for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
+        unsigned op = (unsigned)rp.s_ops[q]; int src = (op >> 14) & 0x1ff, dst = op >> 23;
+        if ((wby[src] >= 0 && wby[src] != w) || (wby[dst] >= 0 && wby[dst] != w) || (rby[dst] & ~(1 << w))) return 3;
+        wby[dst] = w; rby[src] |= 1 << w; rby[dst] |= 1 << w;
+      }
+      if (rp.s_bar[p] || nw == 1) { std::fill(wby.begin(), wby.end(), -1); std::fill(rby.begin(), rby.end(), 0); }
     }
-    for (int b = 0; b < pl.nb; b++) if (writer[b] >= 0 && reader[b] >= 0 && reader[b] != writer[b]) return 3;
-    // a phase that follows a barrier-less boundary must run on the same single wave as its predecessor
-    if (p > 0 && !rp.s_bar[p - 1] && nw > 1 && !(nown <= 1 && (nown == 0 || owner == last_solo))) return 3;
-    last_solo = nown == 1 ? owner : (nown == 0 ? last_solo : -1);
+    if (nw > 1 && !rp.s_bar[rp.nphase - 1]) return 3;
+  }
+  for (int p = 0; p < rp.nphase; p++) {
     for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
       unsigned op = (unsigned)rp.s_ops[q]; int kind = op & 3, slot = (op >> 2) & 0xfff, src = (op >> 14) & 0x1ff, dst = op >> 23;
       const double *B = &S[(size_t)slot * BLK];

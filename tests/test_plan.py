@@ -85,7 +85,7 @@ def _run_res(ls, nw, b=0, seed=0):
     assert rc == 0, rc
     ref = np.linalg.solve(M, rhs)
     assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
-    return dict(ntemp=info[0], nphase=info[1], lds=info[2], barriers=info[3] % 1000, segments=info[3] // 1000)
+    return dict(ntemp=info[0] % 100, ordering=info[0] // 100, nphase=info[1], lds=info[2], barriers=info[3] % 1000, segments=info[3] // 1000)
 
 
 @pytest.mark.parametrize("nw", [1, 4, 8])
@@ -117,3 +117,18 @@ def test_res_plan_rejects_indefinite(built):
     Pv = np.ascontiguousarray(ls.P[0]); Av = np.ascontiguousarray(ls.A[0])
     assert L.plan_execute_res(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), 1, _p(Pv), _p(Av), _p(rho), C.c_double(1e-6),
                               _p(rhs), _p(sol), _p(info)) == 2
+
+
+@pytest.mark.parametrize("nw", [4, 8])
+def test_res_plan_twisted_ordering(built, nw):
+    """two-sided elimination of the stage chain (ordering 2, passed as nw + 200): same block count and LDS footprint,
+    roughly half the phases, still hazard-free and exact"""
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=20)
+    base = _run_res(ls, nw)
+    tw = _run_res(ls, nw + 200)
+    assert base["ordering"] == 1 and tw["ordering"] == 2
+    assert tw["nphase"] <= base["nphase"] // 2 + 3
+    assert abs(tw["lds"] - base["lds"]) < 4096
+    # stage frames that do not tile 16-blocks (cart-pole f = 5) keep the plain hubs-last order
+    mdl, ls, _ = models.make_workload("cartpole", 1, N=30)
+    assert _run_res(ls, nw + 200)["ordering"] == 1
