@@ -89,7 +89,7 @@ __device__ __forceinline__ void ell_rows(const DevEll &E, const double *__restri
     double acc = 0.0;
 #pragma unroll 4
     for (int s = s0; s < s1; s++) {
-      const long e = (long)s * WAVE + lane;
+      const unsigned e = (unsigned)s * WAVE + lane;
       acc += val[e] * in[E.idx[e]];
     }
     f(c * WAVE + lane, acc);
@@ -104,7 +104,7 @@ __device__ __forceinline__ void ell_rowmax(const DevEll &E, const double *__rest
     double acc = 0.0;
 #pragma unroll 4
     for (int s = s0; s < s1; s++) {
-      const long e = (long)s * WAVE + lane;
+      const unsigned e = (unsigned)s * WAVE + lane;
       acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
     }
     f(c * WAVE + lane, acc);
@@ -241,7 +241,7 @@ __device__ bool factorize(Ctx &cx) {
     for (int c = 0; c < E.nchunks; c++) {
       double acc = 0.0;
       for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
-        const long e = (long)s * WAVE + lane;
+        const unsigned e = (unsigned)s * WAVE + lane;
         const double v = valAt[e];
         if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
       }
@@ -257,7 +257,7 @@ __device__ bool factorize(Ctx &cx) {
       const int i = c * WAVE + lane;
       const double sr = sqrt(cx.W[i]);
       for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
-        const long e = (long)s * WAVE + lane;
+        const unsigned e = (unsigned)s * WAVE + lane;
         const int tp = pl.tpos[e];
         if (tp >= 0) T[tp] = valA[e] * sr;
       }
@@ -487,12 +487,12 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
   // apply scaling: A <- E A D, P <- c D P D, q <- c D q, l,u <- E l, E u (bounds clipped to +-1e30 first)
   for (int ch = 0; ch < pl.A.nchunks; ch++) {
     const int i = ch * WAVE + lane; const double ei = cx.W[i];
-    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] *= ei * cx.R[pl.A.idx[e]]; }
+    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valA[e] *= ei * cx.R[pl.A.idx[e]]; }
   }
   for (int ch = 0; ch < pl.At.nchunks; ch++) {
     const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
-    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] *= dj * cx.W[pl.At.idx[e]]; }
-    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] *= c * dj * cx.R[pl.P.idx[e]]; }
+    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valAt[e] *= dj * cx.W[pl.At.idx[e]]; }
+    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valP[e] *= c * dj * cx.R[pl.P.idx[e]]; }
   }
   for (int t = lane; t < npad; t += WAVE) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
   for (int i = lane; i < mpad; i += WAVE) {
@@ -646,33 +646,45 @@ __device__ __forceinline__ void block_combine(double (&v)[K], double *red, int w
   }
 }
 
+// One ELL chunk (64 rows, slots s0..s1) for this lane's row: sum_s val * in[idx]  (or max_s |val| * in[idx]).
+// Pointer bumps + compile-time strides keep the address arithmetic in the loads' immediate offsets (the generic
+// indexed form spent ~12 instructions per slot on 64-bit address math); batches of 8 / 4 / 2 / 1 slots issue all
+// their loads before the first use.
+template <bool MAXABS, int U>
+__device__ __forceinline__ double ell_batch(const double *__restrict__ &vp, const int *__restrict__ &ip, const double *in, double acc) {
+  double v[U]; int ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const double x = in[ix[u]];
+    acc = MAXABS ? fmax(acc, fabs(v[u]) * x) : acc + v[u] * x;
+  }
+  vp += U * WAVE; ip += U * WAVE;
+  return acc;
+}
+template <bool MAXABS>
+__device__ __forceinline__ double ell_chunk(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
+  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
+  const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
+  double acc = 0.0;
+  int rem = s1 - s0;
+  for (; rem >= 16; rem -= 16) acc = ell_batch<MAXABS, 16>(vp, ip, in, acc);
+  if (rem & 8) acc = ell_batch<MAXABS, 8>(vp, ip, in, acc);
+  if (rem & 4) acc = ell_batch<MAXABS, 4>(vp, ip, in, acc);
+  if (rem & 2) acc = ell_batch<MAXABS, 2>(vp, ip, in, acc);
+  if (rem & 1) acc = ell_batch<MAXABS, 1>(vp, ip, in, acc);
+  return acc;
+}
 // ELL sweeps for the multi-wave kernels: wave `wid` takes chunks wid, wid + NW, ... (A 16-deep clamped full unroll
 // and a 4-lanes-per-row split were both measured slower on MI355X: spills / more latency rounds; see DESIGN.md.)
 template <int NW, class F>
 __device__ __forceinline__ void ell_rows_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  for (int c = wid; c < E.nchunks; c += NW) {
-    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
-    double acc = 0.0;
-#pragma unroll 8
-    for (int s = s0; s < s1; s++) {
-      const long e = (long)s * WAVE + lane;
-      acc += val[e] * in[E.idx[e]];
-    }
-    f(c * WAVE + lane, acc);
-  }
+  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<false>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
 }
 template <int NW, class F>
 __device__ __forceinline__ void ell_rowmax_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  for (int c = wid; c < E.nchunks; c += NW) {
-    const int s0 = E.chunk_off[c], s1 = E.chunk_off[c + 1];
-    double acc = 0.0;
-#pragma unroll 8
-    for (int s = s0; s < s1; s++) {
-      const long e = (long)s * WAVE + lane;
-      acc = fmax(acc, fabs(val[e]) * in[E.idx[e]]);
-    }
-    f(c * WAVE + lane, acc);
-  }
+  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<true>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
 }
 
 // sum over the 4 lanes of a quad with DPP quad_perm (no LDS crossbar round trip)
@@ -834,7 +846,7 @@ __device__ bool factorize_res(RCtx &cx) {
     for (int c = wid; c < E.nchunks; c += NW) {
       double acc = 0.0;
       for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
-        const long e = (long)s * WAVE + lane;
+        const unsigned e = (unsigned)s * WAVE + lane;
         const double v = valAt[e];
         if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
       }
@@ -848,7 +860,7 @@ __device__ bool factorize_res(RCtx &cx) {
       const int i = c * WAVE + lane;
       const double sr = sqrt(cx.W[i]);
       for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
-        const long e = (long)s * WAVE + lane;
+        const unsigned e = (unsigned)s * WAVE + lane;
         const int tp = pl.tpos[e];
         if (tp >= 0) T[tp] = valA[e] * sr;
       }
@@ -880,8 +892,14 @@ __device__ bool factorize_res(RCtx &cx) {
   int nprev = 0, prev0 = 0;
   for (int K = 0; K < pl.nb; K++) {
     if (wid == 0) {
+#ifdef MPCQP_TIMING
+      const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+#endif
       const bool ok = sweep_inverse(cx.BL + (long)rs.col_diag[K] * BLK, cx.RB, lane);
       if (lane == 0) cx.RB[16] = ok ? 1.0 : 0.0;
+#ifdef MPCQP_TIMING
+      cx.fts[3] += __builtin_amdgcn_s_memtime() - s0_;
+#endif
     }
     if (NW > 1 && wid > 0) {     // deferred: previous column's W tiles -> their slots
       for (int a = wid - 1; a < nprev; a += NW - 1)
@@ -945,10 +963,8 @@ __device__ void update_info_res(RCtx &cx, Info &in) {
   });
   // P x and A' y land on the same rows for a given wave (both chunked by wid), so no barrier is needed in between
   for (int c = wid; c < pl.P.nchunks; c += NW) {
-    double px = 0.0, aty = 0.0;
-    for (int s = pl.P.chunk_off[c]; s < pl.P.chunk_off[c + 1]; s++) { const long e = (long)s * WAVE + lane; px += valP[e] * cx.X[pl.P.idx[e]]; }
-#pragma unroll 8
-    for (int s = pl.At.chunk_off[c]; s < pl.At.chunk_off[c + 1]; s++) { const long e = (long)s * WAVE + lane; aty += valAt[e] * cx.Y[pl.At.idx[e]]; }
+    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, pl.P.chunk_off[c], pl.P.chunk_off[c + 1], lane);
+    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, pl.At.chunk_off[c], pl.At.chunk_off[c + 1], lane);
     const int t = c * WAVE + lane;
     if (t < pl.npad) {
       const double dinv = unscale ? 1.0 / Dg[t] : 1.0, qv = cx.Q[t], du = qv + px + aty;
@@ -1101,10 +1117,8 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   for (int it = 0; it < st.scaling; it++) {
     for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
       const int t = ch * WAVE + lane;
-      double nA = 0.0, nP = 0.0;
-#pragma unroll 8
-      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nA = fmax(nA, fabs(sAt[e]) * cx.W[pl.At.idx[e]]); }
-      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; nP = fmax(nP, fabs(sP[e]) * cx.R[pl.P.idx[e]]); }
+      const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], lane);
+      const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], lane);
       if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
     }
     ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
@@ -1124,12 +1138,12 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
   for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
     const int i = ch * WAVE + lane; const double ei = cx.W[i];
-    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
+    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
   }
   for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
     const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
-    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
-    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const long e = (long)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
+    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
+    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
   }
   bsync<NW>();
   for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
@@ -1182,16 +1196,26 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
       can_check = st.check_termination && (iter % st.check_termination == 0);
       const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
       const int save = can_check || do_rho;
-      ell_rows_w<NW>(pl.A, valA, cx.R, wid, lane, [&](int i, double zt) {
-        if (i < m) {
-          const double lo = lb[i], up = ub[i], rh = rho_of(lo, up, cx.rho), rinv = 1.0 / rh;
-          const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
-          const double zn = fmin(fmax(zr + rinv * yo, lo), up);
-          const double dy = rh * (zr - zn), yn = yo + dy;
-          cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
-          if (save) dyg[i] = dy;
+      {
+        // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.
+        // l, u are fetched before the row sum is accumulated; rho_i and 1/rho_i are selected from the three values
+        // the rho rule can produce (no per-row division).
+        const double rho_eq = Q_RHO_EQ * cx.rho, ri_min = 1.0 / Q_RHO_MIN, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / cx.rho;
+        for (int c = wid; c < pl.A.nchunks; c += NW) {
+          const int i = c * WAVE + lane;
+          const double lo = lb[i], up = ub[i];
+          const double zt = ell_chunk<false>(valA, pl.A.idx, cx.R, pl.A.chunk_off[c], pl.A.chunk_off[c + 1], lane);
+          if (i < m) {
+            const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
+            const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
+            const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
+            const double zn = fmin(fmax(zr + rinv * yo, lo), up);
+            const double dy = rh * (zr - zn), yn = yo + dy;
+            cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
+            if (save) dyg[i] = dy;
+          }
         }
-      });
+      }
       bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
       for (int t = tid; t < npad; t += NT) {
         const double xo = cx.X[t], xn = alpha * cx.R[t] + (1.0 - alpha) * xo;
@@ -1239,7 +1263,7 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   }
   TS(8);
 #ifdef MPCQP_TIMING
-  ts_acc[12] = cx.fts[0]; ts_acc[13] = cx.fts[1]; ts_acc[14] = cx.fts[2];
+  ts_acc[12] = cx.fts[0]; ts_acc[13] = cx.fts[1]; ts_acc[14] = cx.fts[2]; ts_acc[15] = cx.fts[3];
 #endif
   TS_STORE(io.dbg);
 }
@@ -1375,10 +1399,12 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       if (small_ok && lds_bytes_res(pl, r1) <= 40 * 1024) want = 1;
       else { ResPlan r4 = build_res_plan(pl, 4); want = (small_ok && lds_bytes_res(pl, r4) <= LDS_MAX) ? 4 : 0; }
     }
-    if (want >= 2 && !getenv("MPCQP_NO_TWIST")) {
-      // multi-wave resident kernels: eliminate the stage chain from both ends (two concurrent half-length chains)
-      Plan tw = build_plan(n, m, Pp, Pi, Ap, Ai, 2);
-      if (tw.error.empty() && tw.ordering == 2 && tw.nblk <= h->plan.nblk) { h->plan = tw; h->wl = ws_layout(h->plan); }
+    if (want > 0) {
+      // resident kernels are latency-bound: pad ELL chunk widths to multiples of 4 (fewer load batches per chunk)
+      // and, with several waves, eliminate the stage chain from both ends (two concurrent half-length chains)
+      const bool twist = want >= 2 && !getenv("MPCQP_NO_TWIST");
+      Plan rp2 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, true);
+      if (rp2.error.empty() && rp2.nblk <= h->plan.nblk) { h->plan = rp2; h->wl = ws_layout(h->plan); }
     }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want);

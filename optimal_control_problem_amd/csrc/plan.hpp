@@ -39,7 +39,9 @@ struct Ell {
 
 struct EllEntry { int idx, src, flag; };
 
-inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows) {
+// pad4: round chunk widths above 2 up to a multiple of 4 (zero entries) so that the latency-bound resident kernels
+// need fewer load batches per chunk (17 slots = 16 + 4 instead of 8 + 8 + 1); the streaming kernel keeps exact widths
+inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows, bool pad4 = false) {
   Ell e;
   e.nrows = (int)rows.size();
   e.nchunks = (e.nrows + WAVE - 1) / WAVE;
@@ -47,6 +49,7 @@ inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows) {
   for (int c = 0; c < e.nchunks; c++) {
     size_t w = 0;
     for (int r = c * WAVE; r < std::min(e.nrows, (c + 1) * WAVE); r++) w = std::max(w, rows[r].size());
+    if (pad4 && w > 2) w = (w + 3) / 4 * 4;
     e.chunk_off[c + 1] = e.chunk_off[c] + (int)w;
   }
   e.idx.assign(e.entries(), 0); e.src.assign(e.entries(), -1); e.flag.assign(e.entries(), 0);
@@ -140,7 +143,7 @@ inline int block_fill(int nb, std::vector<std::set<int>> &pat) {
 }  // namespace detail
 
 // Build the plan. P: CSC n x n (entries with row > col ignored), A: CSC m x n.
-inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1) {
+inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1, bool pad4 = false) {
   Plan pl;
   pl.n = n; pl.m = m;
   if (n <= 0 || m < 0 || !Pp || !Ap) { pl.error = "invalid dimensions"; return pl; }
@@ -266,12 +269,12 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
   {
     std::vector<std::vector<EllEntry>> rows(m);
     for (int i = 0; i < m; i++) for (auto &a : arow[i]) rows[i].push_back({pl.pos[a.col], a.src, 0});
-    pl.A = build_ell(rows);
+    pl.A = build_ell(rows, pad4);
   }
   {
     std::vector<std::vector<EllEntry>> rows(pl.npad);
     for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) rows[pl.pos[j]].push_back({Ai[k], k, pl.singleton[Ai[k]]});
-    pl.At = build_ell(rows);
+    pl.At = build_ell(rows, pad4);
   }
   std::map<std::pair<int, int>, int> pent;  // (posrow, poscol) -> P ELL entry
   {

@@ -26,7 +26,7 @@ L = _lib.lib()
 L.mpcqp_debug_timing.argtypes = [C.c_void_p, C.c_void_p]
 _lib.check(L.mpcqp_debug_timing(qp._h, raw.ctypes.data))
 names = ["load", "ruiz", "apply-scale+init", "factor(first)", "At pass", "schedule(solve)", "A pass + x", "check", "store",
-         "-", "-", "-", "f:rho/dvec/T", "f:assemble", "f:LDL", "-"]
+         "-", "-", "-", "f:rho/dvec/T", "f:assemble", "f:LDL", "f:LDL sweeps"]
 tot = out[:, :9].sum(axis=1).mean()
 print("variant", qp.plan_info()["variant"], "kernel %.2f ms for %d QPs, mean iters %.1f, mean cycles/QP %.0f (100 MHz ticks: %s)" % (
     ms, batch, got["iters"].mean(), tot, "s_memtime"))
