@@ -143,6 +143,14 @@ def main():
         value = total / elapsed
         abytes = algorithmic_bytes_per_solve(pinfo["nnzP_triu"], pinfo["nnzA"], ls.n, ls.m)
         achieved = abytes * batch / (kms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if any
+        try:
+            tbl = json.load(open(os.path.join(ROOT, "profiles", "traffic_table.json")))
+            key = "%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"])
+            if key in tbl and not args.force_iters:
+                traffic = tbl[key]["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "QP solves/sec (batched OSQP-ADMM, N=%d)" % N, "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -151,7 +159,7 @@ def main():
                                    "eps_abs=eps_rel=1e-3, cold start" % (mdl.name, mdl.nx, mdl.nu, N, ls.n, ls.m, batch),
                        "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mpcqp_res_kernel" if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
                          "algorithmic_bytes_per_solve": abytes},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
