@@ -439,7 +439,10 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
   cx.pl = &pl; cx.st = &st;
   cx.X = lds; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
   cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
-  cx.S0 = cx.W + pl.mpad; cx.S1 = cx.S0 + BS * 17;
+  // the two 16x17 Cholesky tiles alias the rhs vector R when it is large enough: R only carries the singleton
+  // diagonal during assembly and is rebuilt at the start of every ADMM iteration (one more QP per CU for N = 50)
+  if (pl.npad >= 2 * BS * 17) { cx.S0 = cx.R; cx.S1 = cx.R + BS * 17; }
+  else { cx.S0 = cx.W + pl.mpad; cx.S1 = cx.S0 + BS * 17; }
   double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
   double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
   double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
@@ -612,8 +615,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
 #endif
 struct DevRes {
   int nphase, ntemp;
-  const int *col_diag, *w_ptr, *w_slot, *u_ptr, *u_dst, *u_tmp, *u_b, *g_ptr, *g_seg;
-  int n_seg; long stage;
+  const int *lv_ptr, *lv_diag, *lw_ptr, *lw_slot, *lw_g, *lu_ptr, *lu_dst, *lu_tmp, *lu_b, *g_ptr, *g_seg;
+  int n_seg, nlev; long stage;
 };
 
 template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
@@ -713,7 +716,7 @@ __device__ __forceinline__ d4 mfma_abt_l(const double *A, const double *B, d4 ac
 
 // One wave: in-place inverse of the SPD 16x16 tile `a` (LDS, row-major) by symmetric sweeps; rb = 16 doubles of LDS.
 // Pivots of the sweeps are the Cholesky pivots squared, so "all pivots > 0" is the positive-definiteness test.
-__device__ bool sweep_inverse(double *a, double *rb, int lane) {
+__device__ __forceinline__ bool sweep_inverse(double *a, double *rb, int lane) {
   const int r = lane >> 2, j = lane & 3;
   d4 v = reinterpret_cast<const d4 *>(a)[lane];      // a[r][4j .. 4j+3]
 #pragma unroll
@@ -798,7 +801,7 @@ __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int
   return acc;
 }
 template <int NW>
-__device__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane) {
+__device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane) {
   const int r = lane >> 2, j = lane & 3;
   const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
   double acc = 0.0;
@@ -828,7 +831,7 @@ __device__ void run_schedule(const int4 *segs, const int g0, const int g1, const
 }
 
 template <int NW>
-__device__ bool factorize_res(RCtx &cx) {
+__device__ __forceinline__ bool factorize_res(RCtx &cx) {
   const DevPlan &pl = *cx.pl; const DevRes &rs = *cx.rs; double *ws = cx.ws;
   const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
   const double *lb = ws + pl.o_l, *ub = ws + pl.o_u;
@@ -888,54 +891,48 @@ __device__ bool factorize_res(RCtx &cx) {
 #ifdef MPCQP_TIMING
   unsigned long long f2 = __builtin_amdgcn_s_memtime(); cx.fts[1] += f2 - f1;
 #endif
-  // right-looking block LDL': G_K = S_KK^-1 ; W_IK = S_IK G_K ; S_IJ -= W_IK S_JK'
+  // right-looking block LDL' by elimination-tree levels: G_K = S_KK^-1 (one wave per column of the level);
+  // W_IK = S_IK G_K into temp tiles; S_IJ -= W_IK S_JK' (same-destination updates on one wave); the W tiles replace
+  // the S_IK slots one phase later, once every update that still needs S_JK has read it.
   int nprev = 0, prev0 = 0;
-  for (int K = 0; K < pl.nb; K++) {
-    if (wid == 0) {
+  for (int lev = 0; lev < rs.nlev; lev++) {
+    bool ok = true;
 #ifdef MPCQP_TIMING
-      const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
 #endif
-      const bool ok = sweep_inverse(cx.BL + (long)rs.col_diag[K] * BLK, cx.RB, lane);
-      if (lane == 0) cx.RB[16] = ok ? 1.0 : 0.0;
+    for (int ci = rs.lv_ptr[lev] + wid; ci < rs.lv_ptr[lev + 1]; ci += NW)
+      ok = sweep_inverse(cx.BL + (long)rs.lv_diag[ci] * BLK, cx.RB + 16 * wid, lane) && ok;
 #ifdef MPCQP_TIMING
-      cx.fts[3] += __builtin_amdgcn_s_memtime() - s0_;
+    if (wid == 0) cx.fts[3] += __builtin_amdgcn_s_memtime() - s0_;
 #endif
-    }
-    if (NW > 1 && wid > 0) {     // deferred: previous column's W tiles -> their slots
-      for (int a = wid - 1; a < nprev; a += NW - 1)
-        reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
-    }
+    for (int a = wid; a < nprev; a += NW)
+      reinterpret_cast<d4 *>(cx.BL + (long)rs.lw_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+    if (lane == 0) cx.RED[wid] = ok ? 1.0 : 0.0;
     bsync<NW>();
-    if (cx.RB[16] == 0.0) return false;
-    const int w0 = rs.w_ptr[K], nwk = rs.w_ptr[K + 1] - w0;
-    const double *G = cx.BL + (long)rs.col_diag[K] * BLK;
+    bool all_ok = true;
+    for (int w = 0; w < NW; w++) all_ok = all_ok && cx.RED[w] != 0.0;
+    if (!all_ok) return false;
+    const int w0 = rs.lw_ptr[lev], nwk = rs.lw_ptr[lev + 1] - w0;
     for (int a = wid; a < nwk; a += NW) {
       d4 acc = {0, 0, 0, 0};
-      acc = mfma_abt_l(cx.BL + (long)rs.w_slot[w0 + a] * BLK, G, acc, lane);
+      acc = mfma_abt_l(cx.BL + (long)rs.lw_slot[w0 + a] * BLK, cx.BL + (long)rs.lw_g[w0 + a] * BLK, acc, lane);
       double *t = cx.TMP + (long)a * BLK;
 #pragma unroll
       for (int g = 0; g < 4; g++) t[(row0 + 4 * g) * BS + col] = acc[g];
     }
     bsync<NW>();
-    for (int u = rs.u_ptr[K] + wid; u < rs.u_ptr[K + 1]; u += NW) {
+    for (int u = rs.lu_ptr[lev * NW + wid]; u < rs.lu_ptr[lev * NW + wid + 1]; u++) {
       d4 acc = {0, 0, 0, 0};
-      acc = mfma_abt_l(cx.TMP + (long)rs.u_tmp[u] * BLK, cx.BL + (long)rs.u_b[u] * BLK, acc, lane);
-      double *dst = cx.BL + (long)rs.u_dst[u] * BLK;
+      acc = mfma_abt_l(cx.TMP + (long)rs.lu_tmp[u] * BLK, cx.BL + (long)rs.lu_b[u] * BLK, acc, lane);
+      double *dst = cx.BL + (long)rs.lu_dst[u] * BLK;
 #pragma unroll
       for (int g = 0; g < 4; g++) dst[(row0 + 4 * g) * BS + col] -= acc[g];
     }
     bsync<NW>();
-    if (NW == 1) {
-      for (int a = 0; a < nwk; a++)
-        reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[w0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
-      bsync<NW>();
-    }
     nprev = nwk; prev0 = w0;
   }
-  if (NW > 1) {                  // the last column has no off-diagonal block, but flush defensively
-    for (int a = wid; a < nprev; a += NW)
-      reinterpret_cast<d4 *>(cx.BL + (long)rs.w_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
-  }
+  for (int a = wid; a < nprev; a += NW)   // (the last level has no off-diagonal block; kept for generality)
+    reinterpret_cast<d4 *>(cx.BL + (long)rs.lw_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
   for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
   bsync<NW>();
 #ifdef MPCQP_TIMING
@@ -945,7 +942,7 @@ __device__ bool factorize_res(RCtx &cx) {
 }
 
 template <int NW>
-__device__ void update_info_res(RCtx &cx, Info &in) {
+__device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
   const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane;
   const double *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
   const double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
@@ -981,7 +978,7 @@ __device__ void update_info_res(RCtx &cx, Info &in) {
 }
 
 template <int NW>
-__device__ bool primal_infeasible_res(RCtx &cx, double eps) {
+__device__ __forceinline__ bool primal_infeasible_res(RCtx &cx, double eps) {
   const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
   const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dy = ws + pl.o_dy;
   double v[2] = {0.0, 0.0};   // 0 nrm (max) 1 lhs (sum)
@@ -1014,7 +1011,7 @@ __device__ bool primal_infeasible_res(RCtx &cx, double eps) {
 }
 
 template <int NW>
-__device__ bool dual_infeasible_res(RCtx &cx, double eps) {
+__device__ __forceinline__ bool dual_infeasible_res(RCtx &cx, double eps) {
   const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
   const double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Eg = ws + pl.o_E, *Dg = ws + pl.o_D, *dx = ws + pl.o_dx;
   double v[2] = {0.0, 0.0};   // 0 nrm (max) 1 q'dx (sum)
@@ -1049,7 +1046,7 @@ __device__ bool dual_infeasible_res(RCtx &cx, double eps) {
 }
 
 template <int NW>
-__device__ int check_termination_res(RCtx &cx, Info &in, int approximate) {
+__device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int approximate) {
   const mpcqp_settings &st = *cx.st;
   double eps_abs = st.eps_abs, eps_rel = st.eps_rel, epi = st.eps_prim_inf, edi = st.eps_dual_inf;
   if (in.prim_res > Q_INFTY || in.dual_res > Q_INFTY || in.prim_res != in.prim_res || in.dual_res != in.dual_res) { in.obj = NAN; return MPCQP_NON_CVX; }
@@ -1073,7 +1070,7 @@ __device__ int check_termination_res(RCtx &cx, Info &in, int approximate) {
 }
 
 template <int NW>
-__global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
+__global__ void __launch_bounds__(NW * WAVE, NW <= 4 ? 1 : 2) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -1084,7 +1081,7 @@ __global__ void __launch_bounds__(NW * WAVE) mpcqp_res_kernel(const DevPlan pl, 
   cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK;
   cx.X = cx.BL + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
   cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
-  cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 64;
+  cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
   double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
@@ -1433,8 +1430,10 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   if (h->variant > 0) {
     const ResPlan &rp = h->rplan; DevRes &dr = h->dres;
     dr.nphase = rp.nphase; dr.ntemp = rp.ntemp;
-    UP(upload(h, rp.col_diag, &dr.col_diag)); UP(upload(h, rp.w_ptr, &dr.w_ptr)); UP(upload(h, rp.w_slot, &dr.w_slot));
-    UP(upload(h, rp.u_ptr, &dr.u_ptr)); UP(upload(h, rp.u_dst, &dr.u_dst)); UP(upload(h, rp.u_tmp, &dr.u_tmp)); UP(upload(h, rp.u_b, &dr.u_b));
+    dr.nlev = rp.nlev;
+    UP(upload(h, rp.lv_ptr, &dr.lv_ptr)); UP(upload(h, rp.lv_diag, &dr.lv_diag)); UP(upload(h, rp.lw_ptr, &dr.lw_ptr));
+    UP(upload(h, rp.lw_slot, &dr.lw_slot)); UP(upload(h, rp.lw_g, &dr.lw_g)); UP(upload(h, rp.lu_ptr, &dr.lu_ptr));
+    UP(upload(h, rp.lu_dst, &dr.lu_dst)); UP(upload(h, rp.lu_tmp, &dr.lu_tmp)); UP(upload(h, rp.lu_b, &dr.lu_b));
     UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = res_stage_doubles(pl, rp);
   }
   const WsLayout &w = h->wl;

@@ -106,6 +106,12 @@ struct ResPlan {
   std::vector<int> col_diag;             // [nb]
   std::vector<int> w_ptr, w_slot;        // W_IK = S_IK G_K -> temp tile (index within column)
   std::vector<int> u_ptr, u_dst, u_tmp, u_b;  // S_IJ -= temp(I) * S_JK'
+  // the same factorisation by elimination-tree levels: independent block columns of one level are inverted by
+  // different waves at once and share the W / Schur-update phases (same-destination updates stay on one wave)
+  int nlev = 0;
+  std::vector<int> lv_ptr, lv_diag;      // diagonal slots of the columns of each level
+  std::vector<int> lw_ptr, lw_slot, lw_g;  // W ops per level: temp tile index = position within the level
+  std::vector<int> lu_ptr, lu_dst, lu_tmp, lu_b;  // U ops per (level, wave): lu_ptr[lev * nw + w]
   // solve schedule: ops of phase p, wave w are s_ops[s_ptr[p*nw+w] .. s_ptr[p*nw+w+1])
   std::vector<int> s_ptr, s_ops, s_bar;  // s_bar[p] = 1 if a workgroup barrier must follow phase p
   // the same schedule flattened per wave: op words with SOP_BAR markers where the workgroup synchronises;
@@ -405,6 +411,45 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
     }
     rp.u_ptr.push_back((int)rp.u_dst.size());
   }
+  // ---- level-parallel factor plan
+  {
+    std::vector<int> clev(nb, 0);
+    for (int K = 0; K < nb; K++) for (int I : pl.colrows[K]) clev[I] = std::max(clev[I], clev[K] + 1);
+    rp.nlev = nb ? *std::max_element(clev.begin(), clev.end()) + 1 : 0;
+    rp.lv_ptr.push_back(0); rp.lw_ptr.push_back(0); rp.lu_ptr.push_back(0);
+    int maxw = 0;
+    for (int lev = 0; lev < rp.nlev; lev++) {
+      struct U { int dst, tmp, b; };
+      std::map<int, std::vector<U>> groups;
+      int nwops = 0;
+      for (int K = 0; K < nb; K++) if (clev[K] == lev) {
+        rp.lv_diag.push_back(bid[{K, K}]);
+        const std::vector<int> &rows = pl.colrows[K];
+        const int t0 = nwops;
+        for (size_t a = 0; a < rows.size(); a++) { rp.lw_slot.push_back(bid[{rows[a], K}]); rp.lw_g.push_back(bid[{K, K}]); nwops++; }
+        for (size_t a = 0; a < rows.size(); a++) for (size_t b = 0; b <= a; b++) {
+          const int dst = bid.at({rows[a], rows[b]});
+          groups[dst].push_back({dst, t0 + (int)a, bid[{rows[b], K}]});
+        }
+      }
+      maxw = std::max(maxw, nwops);
+      rp.lv_ptr.push_back((int)rp.lv_diag.size());
+      rp.lw_ptr.push_back((int)rp.lw_slot.size());
+      std::vector<std::vector<U>> gs, per(nw);
+      for (auto &kv : groups) gs.push_back(kv.second);
+      std::stable_sort(gs.begin(), gs.end(), [](const std::vector<U> &a, const std::vector<U> &b) { return a.size() > b.size(); });
+      for (auto &g : gs) {
+        int best = 0;
+        for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w;
+        per[best].insert(per[best].end(), g.begin(), g.end());
+      }
+      for (int w = 0; w < nw; w++) {
+        for (auto &u : per[w]) { rp.lu_dst.push_back(u.dst); rp.lu_tmp.push_back(u.tmp); rp.lu_b.push_back(u.b); }
+        rp.lu_ptr.push_back((int)rp.lu_dst.size());
+      }
+    }
+    rp.ntemp = std::max(rp.ntemp, maxw);
+  }
   // ---- solve schedule: backward ASAP levels at op granularity, forward = mirror image
   std::vector<int> fin(nb, 0);
   int maxlev = -1;
@@ -564,12 +609,13 @@ inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
 }
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
-  return (res_stage_doubles(pl, rp) + 3L * pl.npad + 3L * pl.mpad + 64 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles(pl, rp) + 3L * pl.npad + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {
-  // x, q, r [npad]; z, y, w [mpad]; two padded 16x17 scratch tiles; 64 doubles of reduction scratch
-  return (3L * pl.npad + 3L * pl.mpad + 2L * BS * (BS + 1) + 64) * 8L;
+  // x, q, r [npad]; z, y, w [mpad]; two padded 16x17 scratch tiles (aliased onto r when npad >= 544); 64 spare doubles
+  const long tiles = pl.npad >= 2 * BS * (BS + 1) ? 0 : 2L * BS * (BS + 1);
+  return (3L * pl.npad + 3L * pl.mpad + tiles + 64) * 8L;
 }
 
 }  // namespace mpcqp

@@ -224,18 +224,29 @@ int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, 
       if (pl.blk_diag[b] >= 0 && row == col) C[row * BS + col] += dvec[pl.blk_diag[b] * BS + row];
     }
   }
-  for (int K = 0; K < pl.nb; K++) {
-    double *G = &S[(size_t)rp.col_diag[K] * BLK];
-    if (!sweep_inverse(G)) return 2;
-    int nwk = rp.w_ptr[K + 1] - rp.w_ptr[K];
-    for (int a = 0; a < nwk; a++) {
-      double *t = &tmp[(size_t)a * BLK];
-      std::memset(t, 0, BLK * sizeof(double));
-      gemm_abt(&S[(size_t)rp.w_slot[rp.w_ptr[K] + a] * BLK], G, t, 1.0);   // W = S G  (G symmetric)
+  // level-parallel factor plan (what the resident kernel executes); same-destination Schur updates must share a wave
+  tmp.assign((size_t)std::max(rp.ntemp, 1) * BLK, 0.0);
+  std::vector<int> pend_slot; std::vector<int> pend_tmp;
+  for (int lev = 0; lev < rp.nlev; lev++) {
+    for (int ci = rp.lv_ptr[lev]; ci < rp.lv_ptr[lev + 1]; ci++) if (!sweep_inverse(&S[(size_t)rp.lv_diag[ci] * BLK])) return 2;
+    for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
+    pend_slot.clear(); pend_tmp.clear();
+    const int w0 = rp.lw_ptr[lev], nwk = rp.lw_ptr[lev + 1] - w0;
+    if (nwk > rp.ntemp) return 4;
+    std::vector<double> tnew((size_t)std::max(nwk, 1) * BLK, 0.0);
+    for (int a = 0; a < nwk; a++) gemm_abt(&S[(size_t)rp.lw_slot[w0 + a] * BLK], &S[(size_t)rp.lw_g[w0 + a] * BLK], &tnew[(size_t)a * BLK], 1.0);
+    for (int a = 0; a < nwk; a++) std::memcpy(&tmp[(size_t)a * BLK], &tnew[(size_t)a * BLK], BLK * sizeof(double));
+    std::map<int, int> dst_wave;
+    for (int w = 0; w < nw; w++) for (int u = rp.lu_ptr[lev * nw + w]; u < rp.lu_ptr[lev * nw + w + 1]; u++) {
+      auto it = dst_wave.find(rp.lu_dst[u]);
+      if (it != dst_wave.end() && it->second != w) return 3;
+      dst_wave[rp.lu_dst[u]] = w;
+      for (int a = 0; a < nwk; a++) if (rp.lu_dst[u] == rp.lw_slot[w0 + a]) return 3;   // an update may not hit a slot still holding S_IK of this level
+      gemm_abt(&tmp[(size_t)rp.lu_tmp[u] * BLK], &S[(size_t)rp.lu_b[u] * BLK], &S[(size_t)rp.lu_dst[u] * BLK], -1.0);
     }
-    for (int u = rp.u_ptr[K]; u < rp.u_ptr[K + 1]; u++) gemm_abt(&tmp[(size_t)rp.u_tmp[u] * BLK], &S[(size_t)rp.u_b[u] * BLK], &S[(size_t)rp.u_dst[u] * BLK], -1.0);
-    for (int a = 0; a < nwk; a++) std::memcpy(&S[(size_t)rp.w_slot[rp.w_ptr[K] + a] * BLK], &tmp[(size_t)a * BLK], BLK * sizeof(double));
+    for (int a = 0; a < nwk; a++) { pend_slot.push_back(rp.lw_slot[w0 + a]); pend_tmp.push_back(a); }
   }
+  for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
   std::vector<double> v(pl.npad, 0.0);
   for (int j = 0; j < n; j++) v[pl.pos[j]] = rhs[j];
   // hazard check, independent of the scheduler: since the last workgroup barrier no wave may read or overwrite a

@@ -128,7 +128,7 @@ def test_res_plan_twisted_ordering(built, nw):
     tw = _run_res(ls, nw + 200)
     assert base["ordering"] == 1 and tw["ordering"] == 2
     assert tw["nphase"] <= base["nphase"] // 2 + 3
-    assert abs(tw["lds"] - base["lds"]) < 4096
+    assert abs(tw["lds"] - base["lds"]) < 6144 and tw["lds"] <= 160 * 1024    # two more temp tiles (both columns of a level)
     # stage frames that do not tile 16-blocks (cart-pole f = 5) keep the plain hubs-last order
     mdl, ls, _ = models.make_workload("cartpole", 1, N=30)
     assert _run_res(ls, nw + 200)["ordering"] == 1
