@@ -787,11 +787,32 @@ __device__ __forceinline__ void seg_each(const char *BLb, char *vecb, int b, int
     bb = nb; old = nold; b += db; s += ds; d += dd;
   }
 }
+// SG_IND segments: the ops are mutually independent, so two are in flight at once (loads, FMAs, DPP sums interleave)
+template <bool T, bool SET>
+__device__ __forceinline__ void seg_each2(const char *BLb, char *vecb, int b, int s, int d, const int cnt, const int db, const int ds, const int dd,
+                                          const int offN, const int offT, const int offV, const int offD, const int j) {
+  int k = 0;
+  for (; k + 2 <= cnt; k += 2) {
+    const d4 b0 = load_blk<T>(BLb, b, offN, offT), b1 = load_blk<T>(BLb, b + db, offN, offT);
+    const d4 v0 = *reinterpret_cast<const d4 *>(vecb + s + offV), v1 = *reinterpret_cast<const d4 *>(vecb + s + ds + offV);
+    double o0 = 0.0, o1 = 0.0;
+    if (!SET) { o0 = *reinterpret_cast<const double *>(vecb + d + offD); o1 = *reinterpret_cast<const double *>(vecb + d + dd + offD); }
+    const double s0 = quad_sum(b0[0] * v0[0] + b0[1] * v0[1] + b0[2] * v0[2] + b0[3] * v0[3]);
+    const double s1 = quad_sum(b1[0] * v1[0] + b1[1] * v1[1] + b1[2] * v1[2] + b1[3] * v1[3]);
+    if (j == 0) {
+      *reinterpret_cast<double *>(vecb + d + offD) = SET ? s0 : o0 - s0;
+      *reinterpret_cast<double *>(vecb + d + dd + offD) = SET ? s1 : o1 - s1;
+    }
+    b += 2 * db; s += 2 * ds; d += 2 * dd;
+  }
+  wave_order();
+  if (k < cnt) seg_each<T, SET>(BLb, vecb, b, s, d, cnt - k, db, ds, dd, offN, offT, offV, offD, j, 0.0);
+}
 // the ops accumulate into one destination; returns the per-lane partial sum
 template <bool T>
 __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int b, int s, const int cnt, const int db, const int ds,
                                           const int offN, const int offT, const int offV, double acc) {
-#pragma unroll 2
+#pragma unroll 4
   for (int k = 0; k < cnt; k++) {
     const d4 bb = load_blk<T>(BLb, b, offN, offT);
     const d4 v = *reinterpret_cast<const d4 *>(vecb + s + offV);
@@ -801,7 +822,7 @@ __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int
   return acc;
 }
 template <int NW>
-__device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane) {
+__device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane, long long *trace = nullptr) {
   const int r = lane >> 2, j = lane & 3;
   const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
   double acc = 0.0;
@@ -811,7 +832,11 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
     const int fl = __builtin_amdgcn_readfirstlane(a.w), cnt = __builtin_amdgcn_readfirstlane(c.x);
     const int db = __builtin_amdgcn_readfirstlane(c.y), ds = __builtin_amdgcn_readfirstlane(c.z), dd = __builtin_amdgcn_readfirstlane(c.w);
     if (fl & SG_NOP) { bsync<NW>(); continue; }
-    if (fl & SG_EACH) {
+    if ((fl & (SG_EACH | SG_IND)) == (SG_EACH | SG_IND)) {
+      if (fl & SG_SET) seg_each2<false, true>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
+      else if (fl & SG_T) seg_each2<true, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
+      else seg_each2<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
+    } else if (fl & SG_EACH) {
       if (fl & SG_SET) seg_each<false, true>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, 0.0);
       else if (fl & SG_T) seg_each<true, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
       else seg_each<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
@@ -827,6 +852,9 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
       }
     }
     if (fl & SG_BAR) bsync<NW>();
+#ifdef MPCQP_TIMING
+    if (trace && g - g0 < 60) { trace[2 + 2 * (g - g0)] = (long long)__builtin_amdgcn_s_memtime(); trace[3 + 2 * (g - g0)] = ((long long)fl << 32) | cnt; }
+#endif
   }
 }
 
@@ -1069,8 +1097,10 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
   return MPCQP_UNSOLVED;
 }
 
-template <int NW>
-__global__ void __launch_bounds__(NW * WAVE, NW <= 4 ? 1 : 2) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
+// MINW = waves per SIMD the register allocation must leave room for: 1 when the LDS footprint allows only one QP per
+// CU anyway (the kernel may then use the whole register file), 2 otherwise
+template <int NW, int MINW>
+__global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -1183,7 +1213,7 @@ __global__ void __launch_bounds__(NW * WAVE, NW <= 4 ? 1 : 2) mpcqp_res_kernel(c
 #ifdef MPCQP_TIMING
       long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
       if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
-      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
       if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
 #else
       run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
@@ -1289,6 +1319,7 @@ struct mpcqp_handle {
   mpcqp_settings st;
   Plan plan; WsLayout wl; long lds = 0;
   int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
+  bool wide = false;            // resident kernel instance that may use the whole register file (one QP per CU)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
@@ -1447,9 +1478,10 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   UP(dalloc(h, &h->odbg, (size_t)batch * 16 + 128));
 #endif
 #undef UP
+  h->wide = h->variant == 4 && h->lds > 80 * 1024;
   if (h->lds > 48 * 1024) {
-    const void *fn = h->variant == 1 ? (const void *)mpcqp_res_kernel<1> : h->variant == 4 ? (const void *)mpcqp_res_kernel<4>
-                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8> : (const void *)mpcqp_admm_kernel;
+    const void *fn = h->variant == 1 ? (const void *)mpcqp_res_kernel<1, 2> : h->variant == 4 ? (h->wide ? (const void *)mpcqp_res_kernel<4, 1> : (const void *)mpcqp_res_kernel<4, 2>)
+                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8, 2> : (const void *)mpcqp_admm_kernel;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
       return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
   }
@@ -1518,9 +1550,10 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   DevIO io = h->io;
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   HIPCHK(hipEventRecord(h->ev0, s));
-  if (h->variant == 1) hipLaunchKernelGGL(mpcqp_res_kernel<1>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 4) hipLaunchKernelGGL(mpcqp_res_kernel<4>, dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 8) hipLaunchKernelGGL(mpcqp_res_kernel<8>, dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  if (h->variant == 1) hipLaunchKernelGGL((mpcqp_res_kernel<1, 2>), dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 4 && h->wide) hipLaunchKernelGGL((mpcqp_res_kernel<4, 1>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 8) hipLaunchKernelGGL((mpcqp_res_kernel<8, 2>), dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
   else hipLaunchKernelGGL(mpcqp_admm_kernel, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));

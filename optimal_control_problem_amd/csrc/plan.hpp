@@ -129,7 +129,8 @@ constexpr int SOP_BAR = 3;
 enum { RF_T = 1, RF_SET = 2, RF_FLUSH = 4, RF_BAR = 8, RF_NOP = 16, RF_PRE = 32 };
 // segment flags: SG_EACH = every op writes its own destination; otherwise the ops accumulate into one destination
 // which is written at the segment's end iff SG_END (a run split over several segments carries the partial sum on)
-enum { SG_T = 1, SG_SET = 2, SG_EACH = 4, SG_END = 8, SG_BAR = 16, SG_NOP = 32 };
+// SG_IND: no op of an SG_EACH segment reads a vector block an earlier op of the segment wrote (ops may be interleaved)
+enum { SG_T = 1, SG_SET = 2, SG_EACH = 4, SG_END = 8, SG_BAR = 16, SG_NOP = 32, SG_IND = 64 };
 
 namespace detail {
 
@@ -471,18 +472,22 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
     std::vector<std::vector<SOp>> per(nw);
     std::stable_sort(groups.begin(), groups.end(), [](const std::vector<SOp> &a, const std::vector<SOp> &b) { return a.size() > b.size(); });
     const bool few = (int)groups.size() <= nw;
-    std::vector<char> taken(nw, 0);
-    for (auto &g : groups) {
-      int best = -1;
-      if (few && g.size() == 1 && owner[g[0].src] >= 0 && !taken[owner[g[0].src]]) best = owner[g[0].src];
-      if (best < 0) {
-        best = 0;
-        for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w;
-        if (few && taken[best]) for (int w = 0; w < nw; w++) if (!taken[w]) { best = w; break; }
+    std::vector<char> taken(nw, 0), done(groups.size(), 0);
+    auto place = [&](size_t gi, int w) {
+      taken[w] = 1; done[gi] = 1;
+      per[w].insert(per[w].end(), groups[gi].begin(), groups[gi].end());
+      owner[groups[gi][0].dst] = w;
+    };
+    if (few)   // first the groups that can follow the wave that produced their source block
+      for (size_t gi = 0; gi < groups.size(); gi++) {
+        const auto &g = groups[gi];
+        if (g.size() == 1 && owner[g[0].src] >= 0 && !taken[owner[g[0].src]]) place(gi, owner[g[0].src]);
       }
-      taken[best] = 1;
-      per[best].insert(per[best].end(), g.begin(), g.end());
-      owner[g[0].dst] = best;
+    for (size_t gi = 0; gi < groups.size(); gi++) if (!done[gi]) {
+      int best = -1;
+      for (int w = 0; w < nw; w++) if ((!few || !taken[w]) && (best < 0 || per[w].size() < per[best].size())) best = w;
+      if (best < 0) { best = 0; for (int w = 1; w < nw; w++) if (per[w].size() < per[best].size()) best = w; }
+      place(gi, best);
     }
     return per;
   };
@@ -579,6 +584,10 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
           }
         }
         if (recs[e - 1].f & RF_BAR) flags |= SG_BAR;
+        bool ind = e - i >= 2;
+        for (size_t a = i; a < e && ind; a++) for (size_t b = i; b < a; b++)
+          if (recs[a].s == recs[b].d || recs[a].d == recs[b].d || (recs[a].d == recs[b].s && !(recs[a].s == recs[a].d && a == b))) { ind = false; break; }
+        if (ind) flags |= SG_IND;
       } else {                                    // a run accumulating into one destination
         flags = tflag;
         while (e < recs.size()) {

@@ -38,6 +38,10 @@ print("  per ADMM iteration: At %.0f, solve %.0f, A+x %.0f cycles" % (out[:, 4].
 
 tr = raw[batch * 16:]
 if tr[0] > 0:
-    d = np.diff(tr[:122]); d = d[(d > 0) & (d < 10**7)]
-    print("  wave-0 record trace of one solve (cycles per record, %d records):" % len(d))
-    print("   ", d.tolist())
+    print("  wave-0 solve: %d cycles; per segment (cycles, flags[T=1,SET=2,EACH=4,END=8,BAR=16,NOP=32], ops):" % (tr[1] - tr[0]))
+    prev = tr[0]; out_ = []
+    for g in range(60):
+        t_, meta = tr[2 + 2 * g], tr[3 + 2 * g]
+        if t_ <= 0: break
+        out_.append((int(t_ - prev), int(meta >> 32), int(meta & 0xffffffff))); prev = t_
+    print("   ", out_)
