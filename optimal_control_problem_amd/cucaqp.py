@@ -36,6 +36,7 @@ class CuCaQP:
         self._qp = None
         self._pattern_key = None
         self._result = None
+        self._start = None
 
     # -- dimensions (CuCaQP.cpp:23-41)
     def setDimension(self, numOfVariables, numOfConstraints):
@@ -62,6 +63,17 @@ class CuCaQP:
 
     def setMaxIteration(self, maxIteration):
         self._kw["max_iter"] = int(maxIteration)
+
+    def setPrimalDualStart(self, x0, y0):
+        """extension (the reference's private update* fast path made usable, CuCaQP.cpp:106-161): start the next solve's
+        ADMM from (x0, y0) instead of zero; pass None to return to cold starts"""
+        if x0 is None:
+            self._start = None
+            self._kw.pop("warm_start", None)
+            return
+        self._start = (np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, -1),
+                       np.ascontiguousarray(y0, dtype=np.float64).reshape(self.batch, -1))
+        self._kw["warm_start"] = 1
 
     def setSolverSetting(self, **kw):
         """extension: any field of mpcqp_settings (rho, sigma, alpha, scaling, adaptive_rho, ...)"""
@@ -159,6 +171,8 @@ class CuCaQP:
                                    self._A[0], self._A[1], device=self._device, **kw)
                 self._pattern_key = key
             self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
+            if self._start is not None:
+                self._qp.warm_start(self._start[0], self._start[1])
         except (_lib.MpcqpError, ValueError) as e:
             return _err("Failed to initialize solver. (%s)" % e)
         self.isInitialized_ = True

@@ -1,0 +1,319 @@
+"""Host-API facade: OCPConfig + OptimalControlProblem with the reference's names, YAML keys and call order.
+
+Mirrors reference include/optimal_control_problem/OCP_config/OCPConfig.h:37-85 + src/OCP_config/OCPConfig.cpp and
+include/optimal_control_problem/OptimalControlProblem.h:13-107 + src/OptimalControlProblem.cpp for the CUDA_SQP solve
+method (the IPOPT / qpOASES / MIXED arms are third-party NLP solvers and out of scope).
+
+CasADi is not available here, so the symbolic SX expressions the reference's builders take are replaced by a tiny
+expression layer that covers what a stage-structured OCP needs: variable slices of a frame (OCPConfig.getVariable),
+the reference parameter vector, differences, and a discrete-dynamics call.  genSolver() recognises the resulting
+structure (quadratic tracking cost with diagonal weights, dynamics defects between consecutive frames) and builds the
+batched local-system evaluator (models.StageOCP) that plays the role of the CasADi-generated localSystemFunction_
+(reference src/sqp_solver/SQPOptimizationSolver.cpp:74-77).  One object may drive a batch of independent instances.
+"""
+import numpy as np
+
+from . import models
+from .sqp import SQPOptimizationSolver
+
+
+# ---------------------------------------------------------------------------------------------------- expressions
+class Expr:
+    def __sub__(self, other):
+        return Diff(self, other)
+
+
+class Var(Expr):
+    """slice [start, stop) of the decision vector X = horizon x frameSize (reference OCPConfig.cpp:29-46)"""
+
+    def __init__(self, step, name, start, stop, offset):
+        self.step, self.name, self.start, self.stop, self.offset = step, name, start, stop, offset
+
+    @property
+    def size(self):
+        return self.stop - self.start
+
+
+class Reference(Expr):
+    def __init__(self, size):
+        self.size = size
+
+
+class Diff(Expr):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.size = a.size
+
+
+class Dynamics(Expr):
+    """F(state, input): discrete map given as a NumPy callable on [..., nx], [..., nu] (complex-step differentiable)"""
+
+    def __init__(self, F, state, inp):
+        self.F, self.state, self.inp = F, state, inp
+        self.size = state.size
+
+
+# ---------------------------------------------------------------------------------------------------- OCPConfig
+def _bound_value(v):
+    """'.inf' / '-.inf' strings as the reference handles them (OCPConfig.cpp:152-159); PyYAML already yields floats"""
+    if isinstance(v, str):
+        s = v.strip()
+        if s in (".inf", ".Inf", ".INF"):
+            return float("inf")
+        if s in ("-.inf", "-.Inf", "-.INF"):
+            return float("-inf")
+        return float(s)
+    return float(v)
+
+
+class OCPConfig:
+    def __init__(self, configNode):
+        self.dt_ = float(configNode["discretization_settings"]["dt"])              # OCPConfig.cpp:90
+        self.horizon_ = int(configNode["discretization_settings"]["horizon"])      # :92
+        self.verbose_ = bool(configNode["solver_settings"]["verbose"])             # :94
+        if "OCP_variables" not in configNode or configNode["OCP_variables"] is None:
+            raise ValueError("node [OCP_variables] not found in YAML file")         # :113-116
+        frame = configNode["OCP_variables"]
+        if not isinstance(frame, (list, tuple)):
+            raise ValueError("status_frame should be a sequence")                  # :120-123
+        self.fields, self.fieldOffsets, total = [], {}, 0
+        lower, upper = [], []
+        for var in frame:                                                           # initializeFrame, :56-81
+            if "name" not in var:
+                raise ValueError("Field name not found in frame")
+            if "size" not in var:
+                raise ValueError("Field size not found in frame")
+            name, size = str(var["name"]), int(var["size"])
+            if size <= 0:
+                raise ValueError("Field size must be positive: " + name)
+            self.fields.append((name, size)); self.fieldOffsets[name] = total; total += size
+            for key, dst in (("lower_bound", lower), ("upper_bound", upper)):
+                if key not in var:
+                    raise ValueError("Missing %s for variable: %s" % (key, name))   # :138-141,180-183
+                vals = np.zeros(size)
+                seq = var[key]
+                if isinstance(seq, (list, tuple)):
+                    for i in range(min(len(seq), size)):                            # size mismatch only warns, :147-151
+                        vals[i] = _bound_value(seq[i])
+                dst.append(vals)
+        self.totalSize = total
+        one_lo, one_hi = np.concatenate(lower), np.concatenate(upper)
+        self.lowerBounds_ = [one_lo.copy() for _ in range(self.horizon_)]           # coverLowerBounds: one frame x horizon
+        self.upperBounds_ = [one_hi.copy() for _ in range(self.horizon_)]
+        self.initialGuess_ = None
+
+    def getVariable(self, stepID, variableName):
+        if stepID < 0 or stepID >= self.horizon_:
+            raise IndexError("Frame ID out of range")                               # :30-32
+        if variableName not in self.fieldOffsets:
+            raise ValueError("Field name not found in frame")                       # :33-36
+        size = dict(self.fields)[variableName]
+        start = stepID * self.totalSize + self.fieldOffsets[variableName]
+        return Var(stepID, variableName, start, start + size, self.fieldOffsets[variableName])
+
+    def getVariables(self):
+        return self.horizon_ * self.totalSize
+
+    def getLowerBounds(self):
+        return self.lowerBounds_
+
+    def getUpperBounds(self):
+        return self.upperBounds_
+
+    def getHorizon(self):
+        return self.horizon_
+
+    def getDt(self):
+        return self.dt_
+
+    def getFrameSize(self):
+        return self.totalSize
+
+    def setInitialGuess(self, initialGuess):
+        self.initialGuess_ = np.asarray(initialGuess, float)
+
+    def getInitialGuess(self):
+        return self.initialGuess_
+
+
+# ---------------------------------------------------------------------------------------------------- OptimalControlProblem
+class _FacadeStageOCP(models.StageOCP):
+    name = "facade_ocp"
+
+    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi):
+        self.nx, self.nu, self._F, self._lo, self._hi = nx, nu, F, lo, hi
+        super().__init__(N, dt, Q, R)
+
+    def F(self, s, u):
+        return self._F(s, u)
+
+    def frame_bounds(self):
+        return self._lo, self._hi
+
+
+class OptimalControlProblem:
+    """Abstract base: subclasses implement deployConstraintsAndAddCost() (reference OptimalControlProblem.h:101)."""
+
+    SOLVER_TYPES = ("IPOPT", "SQP", "CUDA_SQP", "MIXED")
+
+    def __init__(self, configNode, batch=1, qp_solver=None):
+        if not self.validateConfig(configNode):
+            raise RuntimeError("Invalid configuration file")                        # OptimalControlProblem.cpp:16-18
+        self.OCPConfigPtr_ = OCPConfig(configNode)
+        s = configNode["solver_settings"]
+        self.solverSettings = dict(maxIter=int(s["max_iter"]), warmStart=bool(s["warm_start"]),
+                                   alpha=float(s["SQP_settings"]["alpha"]), stepNum=int(s["SQP_settings"]["step_num"]),
+                                   verbose=bool(s["verbose"]), genCode=bool(s["gen_code"]), loadLib=bool(s["load_lib"]))
+        method = str(s["solve_method"])
+        if method not in self.SOLVER_TYPES:
+            raise ValueError("Unknown solver type: " + method)                       # :43-45
+        self.solverType = method
+        self.batch = int(batch)
+        self._qp_solver = qp_solver
+        self.constraints_, self.constraintNames_ = [], []
+        self.constraintLowerBounds_, self.constraintUpperBounds_ = [], []
+        self.costs_ = []
+        self.reference_ = None
+        self.firstTime_ = True
+        self.optimalTrajectory_ = None
+        self.OSQPSolverPtr_ = None
+        self.model_ = None
+
+    @staticmethod
+    def validateConfig(config):                                                      # :54-62
+        try:
+            s = config["solver_settings"]
+            return all(k in s for k in ("max_iter", "warm_start", "SQP_settings", "verbose", "gen_code", "load_lib", "solve_method")) \
+                and all(k in s["SQP_settings"] for k in ("alpha", "step_num"))
+        except (KeyError, TypeError):
+            return False
+
+    # -- builders (:444-497,574-600)
+    def setReference(self, size):
+        self.reference_ = Reference(int(size))
+        return self.reference_
+
+    def getReference(self):
+        return self.reference_
+
+    def addScalarCost(self, cost):
+        self.costs_.append(cost)
+
+    def addVectorCost(self, param, cost):
+        param = np.asarray(param, float).ravel()
+        if param.shape[0] != cost.size:
+            print("损失的符号向量和参数向量维度不一致")                                    # :576-579 (prints and returns)
+            return
+        self.addScalarCost(("weighted_square", param, cost))
+
+    def addInequalityConstraint(self, constraintName, lowerBound, expression, upperBound):
+        lowerBound = np.asarray(lowerBound, float).ravel(); upperBound = np.asarray(upperBound, float).ravel()
+        if lowerBound.shape[0] != expression.size or upperBound.shape[0] != expression.size:
+            raise ValueError("SX used for inequality constraints has different dimensions!")   # :452-454
+        self.constraints_.append(expression); self.constraintNames_ += [constraintName] * expression.size
+        self.constraintLowerBounds_.append(lowerBound); self.constraintUpperBounds_.append(upperBound)
+
+    def addEquationConstraint(self, constraintName, leftSX, rightSX=None):
+        if rightSX is not None and leftSX.size != rightSX.size:
+            raise ValueError("SX used for constraints has different dimension!")     # :472-474
+        expr = leftSX if rightSX is None else leftSX - rightSX
+        self.constraints_.append(expr); self.constraintNames_ += [constraintName] * expr.size
+        self.constraintLowerBounds_.append(np.zeros(expr.size)); self.constraintUpperBounds_.append(np.zeros(expr.size))
+
+    def getConstraints(self):
+        return self.constraints_
+
+    def getConstraintLowerBounds(self):
+        return self.constraintLowerBounds_
+
+    def getConstraintUpperBounds(self):
+        return self.constraintUpperBounds_
+
+    def deployConstraintsAndAddCost(self):
+        raise NotImplementedError("pure virtual in the reference (OptimalControlProblem.h:101)")
+
+    # -- genSolver (:224-442), CUDA_SQP arm :391-401
+    def genSolver(self):
+        cfg = self.OCPConfigPtr_
+        if cfg.getVariables() == 0:
+            raise RuntimeError("Status or input variables are empty")
+        if not self.constraints_:
+            raise RuntimeError("Constraints are empty")                              # :231-233
+        if self.solverType != "CUDA_SQP":
+            raise NotImplementedError("solve_method %s relies on third-party NLP solvers (IPOPT / qpOASES) and is out of scope; "
+                                      "use CUDA_SQP" % self.solverType)
+        self.model_ = self._compile_stage_model()
+        options = {"max_iter": self.solverSettings["stepNum"], "alpha": self.solverSettings["alpha"],
+                   "verbose": self.solverSettings["verbose"]}
+        self.OSQPSolverPtr_ = SQPOptimizationSolver(self.model_, options, batch=self.batch, qp_solver=self._qp_solver)
+
+    def _compile_stage_model(self):
+        cfg = self.OCPConfigPtr_
+        N, f = cfg.getHorizon(), cfg.getFrameSize()
+        dyn = [c for c in self.constraints_ if isinstance(c, Diff) and isinstance(c.b, Dynamics)]
+        if len(dyn) != len(self.constraints_) or len(dyn) != N - 1:
+            raise NotImplementedError("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames only")
+        s0, u0, F = dyn[0].b.state, dyn[0].b.inp, dyn[0].b.F
+        nx, nu = s0.size, u0.size
+        if s0.offset != 0 or u0.offset != nx or nx + nu != f:
+            raise NotImplementedError("frame layout must be [state; input]")
+        for k, c in enumerate(dyn):
+            if not (isinstance(c.a, Var) and c.a.step == k + 1 and c.a.name == s0.name and c.b.state.step == k and c.b.inp.step == k and c.b.F is F):
+                raise NotImplementedError("dynamics constraints must link frame k to frame k + 1 in order")
+        Q = np.zeros(nx); R = np.zeros(nu)
+        seenQ, seenR = set(), set()
+        for kind, w, e in self.costs_:
+            if kind != "weighted_square":
+                raise NotImplementedError("only addVectorCost terms are compiled")
+            if isinstance(e, Diff) and isinstance(e.a, Var) and isinstance(e.b, Reference) and e.a.name == s0.name:
+                if seenQ and not np.array_equal(Q, w):
+                    raise NotImplementedError("state weights must be the same at every step")
+                Q = w; seenQ.add(e.a.step)
+            elif isinstance(e, Var) and e.name == u0.name:
+                if seenR and not np.array_equal(R, w):
+                    raise NotImplementedError("input weights must be the same at every step")
+                R = w; seenR.add(e.step)
+            else:
+                raise NotImplementedError("cost term not recognised")
+        if seenQ != set(range(N)) or seenR != set(range(N)):
+            raise NotImplementedError("tracking and input costs must be added for every step")
+        if self.reference_ is None or self.reference_.size != nx:
+            raise NotImplementedError("reference must have the state's dimension")
+        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0])
+
+    # -- computeOptimalTrajectory (:78-222), CUDA_SQP arm
+    def computeOptimalTrajectory(self, frame, reference):
+        cfg = self.OCPConfigPtr_
+        frame = np.asarray(frame, float).reshape(self.batch, -1)
+        reference = np.asarray(reference, float).reshape(self.batch, -1)
+        if frame.shape[1] != cfg.getFrameSize():
+            raise ValueError("State dimension mismatch: received %d, expected %d" % (frame.shape[1], cfg.getFrameSize()))      # :79-84
+        if reference.shape[1] != self.reference_.size:
+            raise ValueError("Reference dimension mismatch: received %d, expected %d" % (reference.shape[1], self.reference_.size))  # :85-90
+        lbx = np.tile(np.concatenate(cfg.getLowerBounds()), (self.batch, 1))
+        ubx = np.tile(np.concatenate(cfg.getUpperBounds()), (self.batch, 1))
+        fs = cfg.getFrameSize()
+        lbx[:, :fs] = frame; ubx[:, :fs] = frame                                       # :95-96 the whole first frame is pinned
+        lbg = np.tile(np.concatenate(self.constraintLowerBounds_), (self.batch, 1))
+        ubg = np.tile(np.concatenate(self.constraintUpperBounds_), (self.batch, 1))
+        x0 = np.zeros((self.batch, cfg.getVariables())) if self.firstTime_ or self.optimalTrajectory_ is None else self.optimalTrajectory_
+        arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, x0=x0, p=reference)
+        if not self.solverInputCheck(arg):
+            raise RuntimeError("Solver input validation failed")                        # :116-118
+        try:
+            res = self.OSQPSolverPtr_.getOptimalSolution(arg)                           # :141
+        except Exception as e:                                                         # :219-221
+            raise RuntimeError("Optimization failed: " + str(e))
+        self.optimalTrajectory_ = res["x"]
+        self.firstTime_ = False
+        return self.optimalTrajectory_
+
+    def solverInputCheck(self, arg):                                                  # :511-552
+        ng = sum(len(b) for b in self.constraintLowerBounds_)
+        nv = self.OCPConfigPtr_.getVariables()
+        ok = arg["lbg"].shape[1] == ng and arg["ubg"].shape[1] == ng and arg["lbx"].shape[1] == nv and \
+            arg["ubx"].shape[1] == nv and arg["x0"].shape[1] == nv and arg["p"].shape[1] == self.reference_.size
+        return bool(ok)
+
+    def getOptimalTrajectory(self):
+        return self.optimalTrajectory_

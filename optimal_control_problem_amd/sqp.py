@@ -38,6 +38,10 @@ class SQPOptimizationSolver:
         self.result_ = {"x": np.zeros((self.batch, nvar)), "f": np.zeros(self.batch)}
         self.timings = {"local_system_ms": 0.0, "qp_ms": 0.0}
         self.last_qp_info = None
+        # extension (BASELINE config 4): warm-start each QP's ADMM from the previous SQP
+        # iteration's solution.  Off by default: the reference cold-starts every QP (CuCaQP.cpp:271-288).
+        self.warm_start_admm = bool(options.get("warm_start_admm", False))
+        self.admm_iterations = []
 
     def setVerbose(self, verbose):
         self.verbose_ = bool(verbose)
@@ -60,6 +64,11 @@ class SQPOptimizationSolver:
             localSystem = self.getLocalSystem(arg)
             t1 = time.perf_counter()
             self.qpSolver_.setSystem(localSystem)
+            if self.warm_start_admm and hasattr(self.qpSolver_, "setPrimalDualStart"):
+                info = self.last_qp_info
+                if info is not None and np.isfinite(info["x"]).all() and np.isfinite(info["y"]).all():
+                    # after the damped update x += alpha * dx the remaining step is (1 - alpha) * dx; duals carry over
+                    self.qpSolver_.setPrimalDualStart((1.0 - self.alpha_) * info["x"], info["y"])
             self.qpSolver_.initSolver()
             self.qpSolver_.solve()
             t2 = time.perf_counter()
@@ -67,6 +76,8 @@ class SQPOptimizationSolver:
             self.timings["qp_ms"] += (t2 - t1) * 1e3
             solution = np.asarray(self.qpSolver_.getSolutionAsDM(), float).reshape(B, -1)
             self.last_qp_info = getattr(self.qpSolver_, "getInfo", lambda: None)()
+            if self.last_qp_info is not None and "iters" in self.last_qp_info:
+                self.admm_iterations.append(np.asarray(self.last_qp_info["iters"]).copy())
             oldRes = self.result_["x"].copy()
             self.result_["x"] = self.result_["x"] + self.alpha_ * solution[:, pSize:]
             self.result_["f"] = self.model.objective(p, self.result_["x"])

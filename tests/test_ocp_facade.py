@@ -1,0 +1,163 @@
+"""Host-API facade (OCPConfig / OptimalControlProblem mirror): YAML semantics, builders, first-frame pinning,
+CUDA_SQP dispatch.  CPU tests use the oracle-backed QP stand-in; the gpu-marked test runs the real engine."""
+import numpy as np
+import pytest
+import yaml
+
+from optimal_control_problem_amd import models
+from optimal_control_problem_amd.ocp import Dynamics, OCPConfig, OptimalControlProblem
+
+# the README example (reference readme.md:43-62: dt 0.005, horizon 20, solve_method CUDA_SQP) completed with the keys the
+# code actually reads (max_iter, warm_start, SQP_settings.{alpha, step_num}, gen_code, load_lib)
+YAML_TEXT = """
+optimal_control_problem:
+  discretization_settings:
+    dt: 0.005
+    horizon: 20
+  solver_settings:
+    verbose: false
+    gen_code: false
+    load_lib: false
+    max_iter: 1000
+    warm_start: true
+    solve_method: CUDA_SQP
+    SQP_settings:
+      alpha: 1.0
+      step_num: 2
+  OCP_variables:
+    - name: "state"
+      size: 2
+      lower_bound: [-.inf, -2.0]
+      upper_bound: [.inf, 2.0]
+    - name: "input"
+      size: 1
+      lower_bound: ["-1.0"]
+      upper_bound: [1.0]
+"""
+
+
+def _node():
+    return yaml.safe_load(YAML_TEXT)["optimal_control_problem"]      # the ctor takes the inner node
+
+
+class DoubleIntegratorOCP(OptimalControlProblem):
+    def deployConstraintsAndAddCost(self):
+        cfg = self.OCPConfigPtr_
+        h = cfg.getDt()
+
+        def F(s, u):
+            return np.stack([s[..., 0] + h * s[..., 1] + 0.5 * h * h * u[..., 0], s[..., 1] + h * u[..., 0]], axis=-1)
+
+        ref = self.setReference(2)
+        for k in range(cfg.getHorizon()):
+            self.addVectorCost([10.0, 1.0], cfg.getVariable(k, "state") - ref)
+            self.addVectorCost([0.1], cfg.getVariable(k, "input"))
+        for k in range(cfg.getHorizon() - 1):
+            self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"),
+                                       Dynamics(F, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+
+
+def test_ocpconfig_yaml_semantics():
+    cfg = OCPConfig(_node())
+    assert (cfg.getHorizon(), cfg.getDt(), cfg.getFrameSize(), cfg.getVariables()) == (20, 0.005, 3, 60)
+    lo, hi = cfg.getLowerBounds(), cfg.getUpperBounds()
+    assert len(lo) == 20 and np.array_equal(lo[7], [-np.inf, -2.0, -1.0]) and np.array_equal(hi[19], [np.inf, 2.0, 1.0])
+    v = cfg.getVariable(3, "input")                                   # X[k * frameSize + offset : + size]
+    assert (v.start, v.stop) == (3 * 3 + 2, 3 * 3 + 3)
+    with pytest.raises(IndexError):
+        cfg.getVariable(20, "state")
+    with pytest.raises(ValueError):
+        cfg.getVariable(0, "nope")
+    bad = _node(); del bad["OCP_variables"][0]["lower_bound"]
+    with pytest.raises(ValueError, match="Missing lower_bound"):
+        OCPConfig(bad)
+    bad = _node(); bad["OCP_variables"][1]["size"] = 0
+    with pytest.raises(ValueError, match="must be positive"):
+        OCPConfig(bad)
+
+
+def test_validate_config_and_solver_type():
+    bad = _node(); del bad["solver_settings"]["SQP_settings"]["alpha"]
+    with pytest.raises(RuntimeError, match="Invalid configuration"):
+        DoubleIntegratorOCP(bad)
+    bad = _node(); bad["solver_settings"]["solve_method"] = "NOPE"
+    with pytest.raises(ValueError, match="Unknown solver type"):
+        DoubleIntegratorOCP(bad)
+    ipopt = _node(); ipopt["solver_settings"]["solve_method"] = "IPOPT"
+    ocp = DoubleIntegratorOCP(ipopt); ocp.deployConstraintsAndAddCost()
+    with pytest.raises(NotImplementedError):
+        ocp.genSolver()
+
+
+def _tick(ocp, B):
+    rng = np.random.default_rng(5)
+    frame = np.concatenate([rng.uniform([-1, -1], [1, 1], size=(B, 2)), np.zeros((B, 1))], axis=1)
+    ref = np.zeros((B, 2))
+    return frame, ref, ocp.computeOptimalTrajectory(frame, ref)
+
+
+def test_plumbing_with_oracle_backend(built):
+    """BASELINE config 0: horizon 20 / dt 0.005 OCP through the YAML facade, batch 1 and 3, no GPU"""
+    from tests.support.oracle_backend import OracleCuCaQP
+    for B in (1, 3):
+        ocp = DoubleIntegratorOCP(_node(), batch=B, qp_solver=OracleCuCaQP(batch=B))
+        ocp.deployConstraintsAndAddCost()
+        ocp.genSolver()
+        assert (ocp.model_.nx, ocp.model_.nu, ocp.model_.n, ocp.model_.m) == (2, 1, 62, 100)
+        frame, ref, traj = _tick(ocp, B)
+        assert traj.shape == (B, 60)
+        assert np.abs(traj[:, :3] - frame).max() < 5e-3                              # first frame pinned
+        assert np.abs(ocp.model_.constraints(traj)).max() < 5e-3                     # linear dynamics hold after a full step
+        X = traj.reshape(B, 20, 3)
+        assert (X[:, 1:, 2] >= -1 - 1e-2).all() and (X[:, 1:, 2] <= 1 + 1e-2).all() and (np.abs(X[:, 1:, 1]) <= 2 + 1e-2).all()
+        with pytest.raises(ValueError, match="State dimension mismatch"):
+            ocp.computeOptimalTrajectory(np.zeros((B, 2)), ref)
+        with pytest.raises(ValueError, match="Reference dimension mismatch"):
+            ocp.computeOptimalTrajectory(frame, np.zeros((B, 3)))
+
+
+def test_facade_model_equals_model_zoo():
+    """the compiled facade model produces the same QP data as the hand-written DoubleIntegrator (same formulation)"""
+    ocp = DoubleIntegratorOCP(_node(), batch=2, qp_solver=object())
+    ocp.deployConstraintsAndAddCost()
+    fm = ocp._compile_stage_model()
+    zm = models.DoubleIntegrator(20, 0.005)
+    rng = np.random.default_rng(1)
+    p = rng.normal(size=(2, 2)); x = rng.normal(size=(2, 60))
+    lbx = np.tile(np.concatenate(ocp.OCPConfigPtr_.getLowerBounds()), (2, 1)); ubx = np.tile(np.concatenate(ocp.OCPConfigPtr_.getUpperBounds()), (2, 1))
+    z = np.zeros((2, 38))
+    a = fm.local_system(p, x, lbx, ubx, z, z); b = zm.local_system(p, x, lbx, ubx, z, z)
+    for k in ("P", "q", "A", "l", "u"):
+        assert np.allclose(getattr(a, k), getattr(b, k), rtol=0, atol=1e-12), k
+    assert np.array_equal(a.Ai, b.Ai) and np.array_equal(a.Pi, b.Pi)
+
+
+@pytest.mark.gpu
+def test_plumbing_on_gpu(built):
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 16
+    g = DoubleIntegratorOCP(_node(), batch=B); g.deployConstraintsAndAddCost(); g.genSolver()
+    c = DoubleIntegratorOCP(_node(), batch=B, qp_solver=OracleCuCaQP(batch=B)); c.deployConstraintsAndAddCost(); c.genSolver()
+    _, _, tg = _tick(g, B); _, _, tc = _tick(c, B)
+    assert np.abs(tg - tc).max() <= 1e-6 * (1 + np.abs(tc).max())
+    g.OSQPSolverPtr_.qpSolver_.close()
+
+
+@pytest.mark.gpu
+def test_admm_warm_start_across_sqp_iterations(built):
+    """BASELINE config 4's mechanism: cart-pole SQP with the ADMM of each QP started from the previous SQP iteration's
+    solution needs fewer ADMM iterations and reaches the same trajectory (within the ADMM tolerance)"""
+    from optimal_control_problem_amd.sqp import SQPOptimizationSolver
+    B = 32
+    mdl, ls, meta = models.make_workload("cartpole", B, N=30)
+    arg = dict(lbx=meta["lbx"], ubx=meta["ubx"], lbg=meta["lbg"], ubg=meta["ubg"], p=meta["p"])
+    cold = SQPOptimizationSolver(mdl, {"max_iter": 8, "alpha": 0.5}, batch=B)
+    warm = SQPOptimizationSolver(mdl, {"max_iter": 8, "alpha": 0.5, "warm_start_admm": True}, batch=B)
+    rc = cold.getOptimalSolution(arg); rw = warm.getOptimalSolution(arg)
+    ic = np.sum([i.sum() for i in cold.admm_iterations[1:]]); iw = np.sum([i.sum() for i in warm.admm_iterations[1:]])
+    assert iw < 0.75 * ic
+    # the two runs stop their QPs at eps = 1e-3 from different starts, so weakly-weighted inputs may differ; what must
+    # agree is the quality of the SQP iterate: objective and dynamics violation
+    assert np.abs(rc["f"] - rw["f"]).max() <= 2e-2 * (1 + np.abs(rc["f"]).max())
+    assert np.abs(mdl.constraints(rw["x"])).max() <= 2 * np.abs(mdl.constraints(rc["x"])).max() + 1e-3
+    cold.qpSolver_.close(); warm.qpSolver_.close()
