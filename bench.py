@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="QPs timed on the host for cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
-    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8"])
+    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4"])
     ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
     args = ap.parse_args()
 
@@ -166,7 +166,9 @@ def main():
                             "admm_iters_per_s": iters_sum / (kms_max * 1e-3),
                             "lds_bytes_per_qp": pinfo["lds_bytes"], "workspace_bytes_per_qp": pinfo["workspace_bytes_per_qp"],
                             "L_blocks": pinfo["L_blocks"], "workload_gen_s": t_gen,
-                            "kernel_variant": {0: "stream (1 wave/QP, factor streamed from HBM)"}.get(pinfo["variant"], "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
+                            "kernel_variant": ("stream (1 wave/QP, Cholesky factor streamed from HBM)" if pinfo["variant"] == 0 else
+                                               "LDL' %d waves/QP, factor blocks streamed from HBM" % (pinfo["variant"] - 100) if pinfo["variant"] >= 100 else
+                                               "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
         if world == 1 and not args.no_cpu_baseline and not args.force_iters:
             # the oracle (CPU port of the same algorithm) on this box's host cores, bounded sample of the same workload

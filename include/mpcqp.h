@@ -112,7 +112,8 @@ const char *mpcqp_strerror(int code);            /* replaces the std::cerr messa
 int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms);
 /* info[0..15]: n, m, batch, npad, mpad, n_blocks(n/16), L_blocks, lds_bytes_per_qp, workspace_bytes_per_qp,
  * ordering(0 natural,1 hubs-last), nnzP_triu, nnzA, T_blocks, factor_ops, ell_slots_total,
- * variant (0 = streaming kernel, NW > 0 = LDS-resident factor with NW waves per QP) */
+ * variant (0 = streaming kernel, NW > 0 = LDS-resident factor with NW waves per QP, 100 + NW = same kernels with
+ * the factor blocks left in the HBM slab) */
 int mpcqp_plan_info(const mpcqp_handle *h, long *info16);
 
 /* Replaces CuCaQP::printSolverData (CuCaQP.cpp:226-269): copies the scaled problem data the kernel holds

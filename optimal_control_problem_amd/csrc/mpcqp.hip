@@ -193,21 +193,23 @@ __device__ __forceinline__ void stream_step(const d4 bb, const int op, double *v
   }
   wsync();
 }
-__device__ void run_stream(const double *__restrict__ blk, const int *__restrict__ ops, const int nops, double *vec) {
+template <int PD>
+__device__ __forceinline__ void run_stream(const double *__restrict__ blk, const int *__restrict__ ops, const int nops, double *vec) {
   const int lane = threadIdx.x, r = lane >> 2, j = lane & 3;
   const d4 *p = reinterpret_cast<const d4 *>(blk) + lane;
-  // 4 blocks (8 KiB) of the stream in flight per wave; 8 measured slower on MI355X (profiles/r01 notes)
-  d4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
-  if (0 < nops) b0 = p[0];
-  if (1 < nops) b1 = p[WAVE];
-  if (2 < nops) b2 = p[2 * WAVE];
-  if (3 < nops) b3 = p[3 * WAVE];
-  for (int t = 0; t < nops; t += 4) {
-    stream_step(b0, ops[t], vec, r, j);
-    if (t + 4 < nops) b0 = p[(long)(t + 4) * WAVE];
-    if (t + 1 < nops) { stream_step(b1, ops[t + 1], vec, r, j); if (t + 5 < nops) b1 = p[(long)(t + 5) * WAVE]; }
-    if (t + 2 < nops) { stream_step(b2, ops[t + 2], vec, r, j); if (t + 6 < nops) b2 = p[(long)(t + 6) * WAVE]; }
-    if (t + 3 < nops) { stream_step(b3, ops[t + 3], vec, r, j); if (t + 7 < nops) b3 = p[(long)(t + 7) * WAVE]; }
+  // PD blocks (2 KiB each) of the stream in flight per wave: 4 when six QPs share a CU (8 measured slower there),
+  // 8 when the LDS footprint leaves only a few waves per CU to cover the HBM latency
+  d4 b[PD];
+#pragma unroll
+  for (int u = 0; u < PD; u++) { b[u] = d4{0, 0, 0, 0}; if (u < nops) b[u] = p[(long)u * WAVE]; }
+  for (int t = 0; t < nops; t += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; u++) {
+      if (t + u < nops) {
+        stream_step(b[u], ops[t + u], vec, r, j);
+        if (t + u + PD < nops) b[u] = p[(long)(t + u + PD) * WAVE];
+      }
+    }
   }
 }
 
@@ -432,7 +434,8 @@ __device__ int check_termination(Ctx &cx, Info &in, int approximate) {
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, const mpcqp_settings st, const DevIO io) {
+template <int PD>
+__global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x, lane = threadIdx.x;
   Ctx cx;
@@ -537,8 +540,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPl
       ell_rows(pl.At, valAt, cx.W, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
       wsync();
       // xtilde = M^-1 rhs
-      run_stream(Lf, pl.fwd_ops, pl.nblk, cx.R);
-      run_stream(Lbk, pl.bwd_ops, pl.nblk, cx.R);
+      run_stream<PD>(Lf, pl.fwd_ops, pl.nblk, cx.R);
+      run_stream<PD>(Lbk, pl.bwd_ops, pl.nblk, cx.R);
       can_check = st.check_termination && (iter % st.check_termination == 0);
       const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
       const int save = can_check || do_rho;
@@ -767,6 +770,29 @@ __device__ __forceinline__ void wave_order() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// blocks streamed from the HBM slab (GB variants): PD blocks of the segment in flight, destination read at use time
+template <bool T, bool SET, int PD>
+__device__ __forceinline__ void seg_each_g(const char *BLb, char *vecb, int b, int s, int d, const int cnt, const int db, const int ds, const int dd,
+                                           const int offN, const int offT, const int offV, const int offD, const int j, double carry) {
+  d4 ring[PD];
+#pragma unroll
+  for (int u = 0; u < PD; u++) { ring[u] = d4{0, 0, 0, 0}; if (u < cnt) ring[u] = load_blk<T>(BLb, b + u * db, offN, offT); }
+  for (int k0 = 0; k0 < cnt; k0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; u++) {
+      if (k0 + u < cnt) {
+        const d4 bb = ring[u];
+        if (k0 + u + PD < cnt) ring[u] = load_blk<T>(BLb, b + (k0 + u + PD) * db, offN, offT);
+        const d4 v = *reinterpret_cast<const d4 *>(vecb + s + offV);
+        const double sum = quad_sum(carry + (bb[0] * v[0] + bb[1] * v[1] + bb[2] * v[2] + bb[3] * v[3]));
+        carry = 0.0;
+        if (j == 0) { double *o = reinterpret_cast<double *>(vecb + d + offD); *o = SET ? sum : *o - sum; }
+        wave_order();
+        s += ds; d += dd;
+      }
+    }
+  }
+}
 // every op writes its own destination: dst_k = (SET ? 0 : dst_k) -/+ B_k * src_k ; `carry` joins the first op
 template <bool T, bool SET>
 __device__ __forceinline__ void seg_each(const char *BLb, char *vecb, int b, int s, int d, const int cnt, const int db, const int ds, const int dd,
@@ -809,10 +835,10 @@ __device__ __forceinline__ void seg_each2(const char *BLb, char *vecb, int b, in
   if (k < cnt) seg_each<T, SET>(BLb, vecb, b, s, d, cnt - k, db, ds, dd, offN, offT, offV, offD, j, 0.0);
 }
 // the ops accumulate into one destination; returns the per-lane partial sum
-template <bool T>
+template <bool T, bool GB>
 __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int b, int s, const int cnt, const int db, const int ds,
                                           const int offN, const int offT, const int offV, double acc) {
-#pragma unroll 4
+#pragma unroll 8
   for (int k = 0; k < cnt; k++) {
     const d4 bb = load_blk<T>(BLb, b, offN, offT);
     const d4 v = *reinterpret_cast<const d4 *>(vecb + s + offV);
@@ -821,7 +847,7 @@ __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int
   }
   return acc;
 }
-template <int NW>
+template <int NW, bool GB>
 __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane, long long *trace = nullptr) {
   const int r = lane >> 2, j = lane & 3;
   const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
@@ -832,7 +858,12 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
     const int fl = __builtin_amdgcn_readfirstlane(a.w), cnt = __builtin_amdgcn_readfirstlane(c.x);
     const int db = __builtin_amdgcn_readfirstlane(c.y), ds = __builtin_amdgcn_readfirstlane(c.z), dd = __builtin_amdgcn_readfirstlane(c.w);
     if (fl & SG_NOP) { bsync<NW>(); continue; }
-    if ((fl & (SG_EACH | SG_IND)) == (SG_EACH | SG_IND)) {
+    if (GB && (fl & SG_EACH)) {
+      if (fl & SG_SET) seg_each_g<false, true, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, 0.0);
+      else if (fl & SG_T) seg_each_g<true, false, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      else seg_each_g<false, false, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      acc = 0.0;
+    } else if ((fl & (SG_EACH | SG_IND)) == (SG_EACH | SG_IND)) {
       if (fl & SG_SET) seg_each2<false, true>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
       else if (fl & SG_T) seg_each2<true, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
       else seg_each2<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
@@ -842,8 +873,8 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
       else seg_each<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
       acc = 0.0;
     } else {
-      acc = (fl & SG_T) ? seg_run<true>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc)
-                        : seg_run<false>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc);
+      acc = (fl & SG_T) ? seg_run<true, GB>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc)
+                        : seg_run<false, GB>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc);
       if (fl & SG_END) {
         const double sum = quad_sum(acc);
         acc = 0.0;
@@ -1099,7 +1130,9 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 
 // MINW = waves per SIMD the register allocation must leave room for: 1 when the LDS footprint allows only one QP per
 // CU anyway (the kernel may then use the whole register file), 2 otherwise
-template <int NW, int MINW>
+// GB = the factor blocks stay in the per-QP HBM slab (factors that do not fit LDS); LDS then holds only the temp
+// tiles, the ADMM vectors and the schedule, and the segment loops keep several blocks in flight.
+template <int NW, int MINW, bool GB>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
@@ -1108,13 +1141,14 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   RCtx cx;
   cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
   cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
-  cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK;
-  cx.X = cx.BL + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
+  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
+  if (GB) { cx.BL = ws + pl.o_Lf; cx.TMP = lds; }
+  else { cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK; }
+  cx.X = lds + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
   cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
-  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
   double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
   double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
   const double *inP = io.P + (long)b * io.sP, *inA = io.A + (long)b * io.sA, *inq = io.q + (long)b * io.sq;
@@ -1128,7 +1162,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   // ---- load: caller's CSC values -> ELL arrays. The block region of LDS is idle until the factorisation, so the
   // ELL values of A, A', P live there for the whole scaling phase (host guarantees they fit) and are written to
   // the HBM slab once, already scaled.
-  double *sA = cx.BL, *sAt = sA + pl.A.entries, *sP = sAt + pl.At.entries;
+  double *sA = GB ? valA : lds, *sAt = GB ? valAt : sA + pl.A.entries, *sP = GB ? valP : sAt + pl.At.entries;
   for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
   for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }
   for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
@@ -1213,10 +1247,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
 #ifdef MPCQP_TIMING
       long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
       if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
-      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
+      run_schedule<NW, GB>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
       if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
 #else
-      run_schedule<NW>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+      run_schedule<NW, GB>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
 #endif
       if (NW == 1) bsync<NW>();
       TS(5);
@@ -1320,6 +1354,8 @@ struct mpcqp_handle {
   Plan plan; WsLayout wl; long lds = 0;
   int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
   bool wide = false;            // resident kernel instance that may use the whole register file (one QP per CU)
+  bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
+  bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
@@ -1420,23 +1456,34 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     if (const char *e = getenv("MPCQP_VARIANT")) {
       std::string v(e);
       if (v == "stream") want = 0; else if (v == "res1") want = 1; else if (v == "res4") want = 4; else if (v == "res8") want = 8;
+      else if (v == "gres4") { want = 4; h->gblocks = true; }
     }
-    ResPlan r1 = build_res_plan(pl, 1);
+    // candidate plans of the multi-wave kernels: ELL chunk widths padded to multiples of 4 (fewer load batches per chunk)
+    // and the stage chain eliminated from both ends (two concurrent half-length chains)
+    const bool twist = !getenv("MPCQP_NO_TWIST");
+    Plan p1 = build_plan(n, m, Pp, Pi, Ap, Ai, -1, true);
+    Plan p4 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, true);
+    if (!p1.error.empty() || p1.nblk > h->plan.nblk) p1 = h->plan;
+    if (!p4.error.empty() || p4.nblk > h->plan.nblk) p4 = p1;
     const bool small_ok = pl.nblk < 4096 && pl.nb < 512;
     if (want < 0) {
-      if (small_ok && lds_bytes_res(pl, r1) <= 40 * 1024) want = 1;
-      else { ResPlan r4 = build_res_plan(pl, 4); want = (small_ok && lds_bytes_res(pl, r4) <= LDS_MAX) ? 4 : 0; }
+      // measured on MI355X: one wave per QP with the factor in LDS when it is tiny; four waves per QP
+      // with the factor in LDS when at least two QPs fit per CU; otherwise occupancy beats residency and the factor
+      // blocks are streamed from the HBM slab by the same LDL' / segment machinery (several workgroups per CU)
+      ResPlan r1 = build_res_plan(p1, 1);
+      if (small_ok && lds_bytes_res(p1, r1) <= 40 * 1024) want = 1;
+      else {
+        ResPlan r4 = build_res_plan(p4, 4);
+        if (small_ok && lds_bytes_res(p4, r4) <= 80 * 1024) want = 4;
+        else if (small_ok && lds_bytes_res_gb(p4, r4) <= LDS_MAX) { want = 4; h->gblocks = true; }
+        else want = 0;
+      }
     }
-    if (want > 0) {
-      // resident kernels are latency-bound: pad ELL chunk widths to multiples of 4 (fewer load batches per chunk)
-      // and, with several waves, eliminate the stage chain from both ends (two concurrent half-length chains)
-      const bool twist = want >= 2 && !getenv("MPCQP_NO_TWIST");
-      Plan rp2 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, true);
-      if (rp2.error.empty() && rp2.nblk <= h->plan.nblk) { h->plan = rp2; h->wl = ws_layout(h->plan); }
-    }
+    if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want);
-      const long need = lds_bytes_res(pl, h->rplan);
+      const long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      h->occ4 = h->gblocks && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
     }
@@ -1465,7 +1512,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     UP(upload(h, rp.lv_ptr, &dr.lv_ptr)); UP(upload(h, rp.lv_diag, &dr.lv_diag)); UP(upload(h, rp.lw_ptr, &dr.lw_ptr));
     UP(upload(h, rp.lw_slot, &dr.lw_slot)); UP(upload(h, rp.lw_g, &dr.lw_g)); UP(upload(h, rp.lu_ptr, &dr.lu_ptr));
     UP(upload(h, rp.lu_dst, &dr.lu_dst)); UP(upload(h, rp.lu_tmp, &dr.lu_tmp)); UP(upload(h, rp.lu_b, &dr.lu_b));
-    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = res_stage_doubles(pl, rp);
+    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = h->gblocks ? res_stage_doubles_gb(rp) : res_stage_doubles(pl, rp);
   }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
@@ -1480,8 +1527,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
 #undef UP
   h->wide = h->variant == 4 && h->lds > 80 * 1024;
   if (h->lds > 48 * 1024) {
-    const void *fn = h->variant == 1 ? (const void *)mpcqp_res_kernel<1, 2> : h->variant == 4 ? (h->wide ? (const void *)mpcqp_res_kernel<4, 1> : (const void *)mpcqp_res_kernel<4, 2>)
-                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8, 2> : (const void *)mpcqp_admm_kernel;
+    const void *fn = h->gblocks ? (h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true> : (const void *)mpcqp_res_kernel<4, 2, true>)
+                     : h->variant == 1 ? (const void *)mpcqp_res_kernel<1, 2, false> : h->variant == 4 ? (h->wide ? (const void *)mpcqp_res_kernel<4, 1, false> : (const void *)mpcqp_res_kernel<4, 2, false>)
+                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8, 2, false> : (h->lds > 40 * 1024 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
       return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
   }
@@ -1550,11 +1598,14 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   DevIO io = h->io;
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   HIPCHK(hipEventRecord(h->ev0, s));
-  if (h->variant == 1) hipLaunchKernelGGL((mpcqp_res_kernel<1, 2>), dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 4 && h->wide) hipLaunchKernelGGL((mpcqp_res_kernel<4, 1>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 8) hipLaunchKernelGGL((mpcqp_res_kernel<8, 2>), dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else hipLaunchKernelGGL(mpcqp_admm_kernel, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  if (h->gblocks && h->occ4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 4, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->gblocks) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 1) hipLaunchKernelGGL((mpcqp_res_kernel<1, 2, false>), dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 4 && h->wide) hipLaunchKernelGGL((mpcqp_res_kernel<4, 1, false>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2, false>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->variant == 8) hipLaunchKernelGGL((mpcqp_res_kernel<8, 2, false>), dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
   h->last_stream = s; h->solved = true;
@@ -1609,7 +1660,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
   o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
-  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->variant;
+  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->gblocks ? 100 + h->variant : h->variant;
   return MPCQP_OK;
 }
 

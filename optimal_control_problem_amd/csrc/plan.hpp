@@ -616,6 +616,12 @@ inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
   const long blocks = ((long)pl.nblk + rp.ntemp) * BLK, ell = pl.A.entries() + pl.At.entries() + pl.P.entries();
   return (std::max(blocks, ell) + 15) / 16 * 16;
 }
+// the same kernels with the factor blocks left in the HBM slab: LDS holds temp tiles + vectors + schedule only
+inline long res_stage_doubles_gb(const ResPlan &rp) { return ((long)rp.ntemp * BLK + 15) / 16 * 16; }
+inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp) {
+  const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;
+  return (res_stage_doubles_gb(rp) + 3L * pl.npad + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+}
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
   return (res_stage_doubles(pl, rp) + 3L * pl.npad + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
