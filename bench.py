@@ -160,6 +160,9 @@ def main():
                        "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # the same launch priced on its measured HBM traffic instead of the algorithmic bytes
+                         "achieved_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9,
+                         "frac_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel": "mpcqp_res_kernel" if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
                          "algorithmic_bytes_per_solve": abytes},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
