@@ -125,6 +125,59 @@ int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c)
 int mpcqp_debug_blockops(const double *A, const double *B, const double *C, const double *S,
                          double *out_gemm, double *out_linv, int *potrf_fail);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Local-system evaluation on device.
+ *
+ * Replaces SQPOptimizationSolver::getLocalSystem (reference src/sqp_solver/SQPOptimizationSolver.cpp:100-120): the
+ * CasADi function localSystemFunction_(p, x, l, u) -> (H, grad f, J_c, l - c, u - c) built at
+ * SQPOptimizationSolver.cpp:47-77 with augmented variables w = [p; x] and rows c = [p; x; g(p, x)], evaluated at the
+ * current SQP iterate.  Here the evaluation is a HIP kernel over a batch of instances of one stage OCP
+ *     min sum_k (s_k - p)' Q (s_k - p) + u_k' R u_k   s.t.  s_{k+1} = F(s_k, u_k),   frame_k = [s_k; u_k], k < horizon
+ * (cost as OptimalControlProblem::addVectorCost sums it, reference src/OptimalControlProblem.cpp:574-600; dynamics rows
+ * as addEquationConstraint stacks them, :448-470; stage-interleaved frames, src/OCP_config/OCPConfig.cpp:29-46,102),
+ * and its outputs are written straight into the device arrays mpcqp_update borrows (MPCQP_MEM_DEVICE), in the CSC value
+ * order of mpcqp_stage_pattern -- so an SQP iteration never leaves the GPU.  Jacobians of F come from forward-mode dual
+ * numbers inside the kernel (one thread per instance and QP column), not from finite differences.
+ * np = nx (p is the reference state), n = np + horizon * (nx + nu), m = n + (horizon - 1) * nx. */
+#define MPCQP_MODEL_DOUBLE_INTEGRATOR 0   /* nx 2, nu 1, exact discrete map; no parameters                       */
+#define MPCQP_MODEL_QUADROTOR 1           /* nx 12, nu 4, RK4; par = {mass, grav, arm, kappa, Jx, Jy, Jz}        */
+#define MPCQP_MODEL_CARTPOLE 2            /* nx 4, nu 1, RK4; par = {m_cart, m_pole, length, grav}               */
+
+typedef struct mpcqp_stage_desc {
+  int model;        /* MPCQP_MODEL_*            */
+  int horizon;      /* number of frames N >= 2  */
+  double dt;        /* step of the discrete map */
+  double Q[16];     /* diagonal state weights (first nx used)  */
+  double R[8];      /* diagonal input weights (first nu used)  */
+  double par[8];    /* model parameters, see MPCQP_MODEL_*     */
+  int device;       /* HIP device ordinal, -1 = current device */
+} mpcqp_stage_desc;
+
+typedef struct mpcqp_stage mpcqp_stage;
+
+/* fills `d` with the zoo's defaults for `model` (weights, parameters and dt of SURVEY.md section 8d) */
+int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d);
+/* the once-per-problem part (the reference's constructor builds the symbolic function once, SQPOptimizationSolver.cpp:12-92) */
+int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out);
+void mpcqp_stage_destroy(mpcqp_stage *s);
+/* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
+int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);
+/* CSC sparsity of P (n x n, both triangles, as CasADi hands it to CuCaQP) and A = [I; dg/dw] (m x n): the arrays
+ * mpcqp_create takes.  Pp, Ap: n + 1 entries; Pi: nnz(P); Ai: nnz(A).  Host pointers. */
+int mpcqp_stage_pattern(const mpcqp_stage *s, int *Pp, int *Pi, int *Ap, int *Ai);
+/* getLocalSystem for `batch` instances.  All pointers are device memory, instance-major and dense: p [batch*np],
+ * x, lbx, ubx [batch*horizon*(nx+nu)], lbg, ubg [batch*(horizon-1)*nx]  ->  P [batch*nnzP], q [batch*n],
+ * A [batch*nnzA], l, u [batch*m] with l = [p; lbx; lbg] - c, u = [p; ubx; ubg] - c.  Asynchronous on `stream`. */
+int mpcqp_stage_eval(mpcqp_stage *s, int batch, const double *p, const double *x,
+                     const double *lbx, const double *ubx, const double *lbg, const double *ubg,
+                     double *P, double *q, double *A, double *l, double *u, void *stream);
+/* objective f [batch] (SQPOptimizationSolver.cpp:180-181) and max-norm of the dynamics violation gmax [batch]
+ * (either may be NULL) at iterate x; device pointers */
+int mpcqp_stage_merit(mpcqp_stage *s, int batch, const double *p, const double *x, double *f, double *gmax, void *stream);
+/* the damped update result.x += alpha * solution[pSize:] (SQPOptimizationSolver.cpp:171-177): x [batch*nvar] +=
+ * alpha * dw[b*n + np ...]; device pointers.  step_max [batch] (may be NULL) receives max|alpha * dx| per instance. */
+int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,13 @@
+// common.hpp -- helpers shared by the translation units of libmpcqp.so (not part of the ABI)
+#pragma once
+#include <string>
+#include <hip/hip_runtime.h>
+#include "../../include/mpcqp.h"
+
+// records the message mpcqp_strerror() appends, returns `code` (defined in mpcqp.hip)
+__attribute__((visibility("hidden"))) int mpcqp_set_error(int code, const std::string &msg);
+// picks / validates the device like mpcqp_create: ordinal < 0 = current device; must be gfx950
+__attribute__((visibility("hidden"))) int mpcqp_pick_device(int requested, int *device);
+
+#define MPCQP_HIPCHK(expr)                                                                                              \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mpcqp_set_error(MPCQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)

@@ -27,6 +27,7 @@
 
 #include "../../include/mpcqp.h"
 #include "plan.hpp"
+#include "common.hpp"
 
 using namespace mpcqp;
 
@@ -1345,6 +1346,20 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_blockops_kernel(const d
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+int mpcqp_set_error(int code, const std::string &msg) { return fail(code, msg); }
+int mpcqp_pick_device(int requested, int *device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPCQP_ERR_NO_GPU, "hipGetDeviceCount found no device");
+  int dev = requested;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) return fail(MPCQP_ERR_ARG, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MPCQP_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(MPCQP_ERR_NO_GPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  *device = dev;
+  return MPCQP_OK;
+}
 #define HIPCHK(expr)                                                                              \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MPCQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 

@@ -1,0 +1,148 @@
+// stage_models.hpp -- the stage-OCP model zoo as scalar-generic functors (host + device).
+//
+// In the reference the dynamics are CasADi SX expressions that SQPOptimizationSolver differentiates symbolically
+// (reference src/sqp_solver/SQPOptimizationSolver.cpp:47-77, AutoDifferentiator.cpp:99-140).  Here every model is a
+// template over the scalar type: instantiated with double it evaluates, with Dual it carries one directional
+// derivative (forward mode), which is how the device kernels obtain one Jacobian column per thread.
+// The expressions follow optimal_control_problem_amd/models.py operation by operation (same association order), so
+// host and device values agree to rounding of sin/cos.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define SM_HD __host__ __device__ __forceinline__
+#else
+#define SM_HD inline
+#endif
+
+struct Dual { double v, d; };
+SM_HD Dual mk(double v) { return {v, 0.0}; }
+SM_HD Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+SM_HD Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+SM_HD Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+SM_HD Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+SM_HD Dual operator+(Dual a, double b) { return {a.v + b, a.d}; }
+SM_HD Dual operator+(double a, Dual b) { return {a + b.v, b.d}; }
+SM_HD Dual operator-(Dual a, double b) { return {a.v - b, a.d}; }
+SM_HD Dual operator-(double a, Dual b) { return {a - b.v, -b.d}; }
+SM_HD Dual operator*(Dual a, double b) { return {a.v * b, a.d * b}; }
+SM_HD Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
+SM_HD Dual operator/(Dual a, double b) { return {a.v / b, a.d / b}; }
+SM_HD Dual operator/(double a, Dual b) { const double q = a / b.v; return {q, -q * b.d / b.v}; }
+SM_HD Dual sm_sin(Dual a) { return {sin(a.v), cos(a.v) * a.d}; }
+SM_HD Dual sm_cos(Dual a) { return {cos(a.v), -sin(a.v) * a.d}; }
+SM_HD double sm_sin(double a) { return sin(a); }
+SM_HD double sm_cos(double a) { return cos(a); }
+SM_HD double sm_val(double a) { return a; }
+SM_HD double sm_val(Dual a) { return a.v; }
+SM_HD double sm_der(double) { return 0.0; }
+SM_HD double sm_der(Dual a) { return a.d; }
+
+enum { SM_DOUBLE_INTEGRATOR = 0, SM_QUADROTOR = 1, SM_CARTPOLE = 2, SM_NMODELS = 3 };
+constexpr int SM_MAXNX = 16, SM_MAXNU = 8, SM_NPAR = 8;
+
+// continuous dynamics + RK4 over dt (models.py StageOCP.F); models with a closed-form discrete map override F
+template <class M, class T>
+SM_HD void sm_rk4(const double *par, double h, const T *s, const T *u, T *out) {
+  constexpr int nx = M::nx;
+  T k[nx], acc[nx], st[nx];
+  M::cdyn(par, s, u, k);
+#pragma unroll
+  for (int i = 0; i < nx; i++) { acc[i] = k[i]; st[i] = s[i] + (0.5 * h) * k[i]; }
+  M::cdyn(par, st, u, k);
+#pragma unroll
+  for (int i = 0; i < nx; i++) { acc[i] = acc[i] + 2.0 * k[i]; st[i] = s[i] + (0.5 * h) * k[i]; }
+  M::cdyn(par, st, u, k);
+#pragma unroll
+  for (int i = 0; i < nx; i++) { acc[i] = acc[i] + 2.0 * k[i]; st[i] = s[i] + h * k[i]; }
+  M::cdyn(par, st, u, k);
+#pragma unroll
+  for (int i = 0; i < nx; i++) out[i] = s[i] + (h / 6.0) * (acc[i] + k[i]);
+}
+
+// nx = 2, nu = 1; exact zero-order-hold map (models.py DoubleIntegrator.F); no parameters
+struct SmDoubleIntegrator {
+  static constexpr int nx = 2, nu = 1;
+  template <class T> SM_HD static void F(const double *, double h, const T *s, const T *u, T *out) {
+    out[0] = s[0] + h * s[1] + ((0.5 * h) * h) * u[0];
+    out[1] = s[1] + h * u[0];
+  }
+};
+
+// 12-state quadrotor (models.py Quadrotor.cdyn); par = {mass, grav, arm, kappa, Jx, Jy, Jz}
+struct SmQuadrotor {
+  static constexpr int nx = 12, nu = 4;
+  template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
+    const double mass = par[0], grav = par[1], arm = par[2], kappa = par[3], Jx = par[4], Jy = par[5], Jz = par[6];
+    const T cph = sm_cos(s[3]), sph = sm_sin(s[3]), cth = sm_cos(s[4]), sth = sm_sin(s[4]), cps = sm_cos(s[5]), sps = sm_sin(s[5]);
+    const T tth = sth / cth;
+    const T thrust = u[0] + u[1] + u[2] + u[3];
+    const T a = thrust / mass;
+    const T p_ = s[9], q_ = s[10], r_ = s[11];
+    ds[0] = s[6]; ds[1] = s[7]; ds[2] = s[8];
+    ds[3] = p_ + sph * tth * q_ + cph * tth * r_;
+    ds[4] = cph * q_ - sph * r_;
+    ds[5] = (sph * q_ + cph * r_) / cth;
+    ds[6] = a * (cps * sth * cph + sps * sph);
+    ds[7] = a * (sps * sth * cph - cps * sph);
+    ds[8] = a * (cth * cph) - grav;
+    const T tx = arm * (u[3] - u[1]), ty = arm * (u[2] - u[0]), tz = kappa * (u[0] - u[1] + u[2] - u[3]);
+    ds[9] = (tx - (Jz - Jy) * q_ * r_) / Jx;
+    ds[10] = (ty - (Jx - Jz) * p_ * r_) / Jy;
+    ds[11] = (tz - (Jy - Jx) * p_ * q_) / Jz;
+  }
+  template <class T> SM_HD static void F(const double *par, double h, const T *s, const T *u, T *out) { sm_rk4<SmQuadrotor, T>(par, h, s, u, out); }
+};
+
+// cart-pole, s = [x, theta, xdot, thetadot], theta = 0 upright (models.py CartPole.cdyn); par = {mc, mp, length, grav}
+struct SmCartPole {
+  static constexpr int nx = 4, nu = 1;
+  template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
+    const double mc = par[0], mp = par[1], len = par[2], grav = par[3];
+    const T sn = sm_sin(s[1]), cs = sm_cos(s[1]);
+    const T thd = s[3];
+    const double tot = mc + mp;
+    const T tmp = (u[0] + (mp * len) * thd * thd * sn) / tot;
+    const T thdd = (grav * sn - cs * tmp) / (len * (4.0 / 3.0 - mp * cs * cs / tot));
+    const T xdd = tmp - (mp * len) * thdd * cs / tot;
+    ds[0] = s[2]; ds[1] = s[3]; ds[2] = xdd; ds[3] = thdd;
+  }
+  template <class T> SM_HD static void F(const double *par, double h, const T *s, const T *u, T *out) { sm_rk4<SmCartPole, T>(par, h, s, u, out); }
+};
+
+// ---------------------------------------------------------------------------------------------- host-side structure
+inline void sm_model_dims(int model, int *nx, int *nu) {
+  switch (model) {
+    case SM_DOUBLE_INTEGRATOR: *nx = SmDoubleIntegrator::nx; *nu = SmDoubleIntegrator::nu; break;
+    case SM_QUADROTOR: *nx = SmQuadrotor::nx; *nu = SmQuadrotor::nu; break;
+    case SM_CARTPOLE: *nx = SmCartPole::nx; *nu = SmCartPole::nu; break;
+    default: *nx = *nu = 0;
+  }
+}
+
+// CSC structure of the local system in the reference's formulation (w = [p; x], rows [p; x; g],
+// reference src/sqp_solver/SQPOptimizationSolver.cpp:47-77), rows ascending inside a column:
+//   P column p_i: rows p_i, s_0[i] .. s_{N-1}[i];  column s_k[i]: rows p_i, s_k[i];  column u_k[i]: row u_k[i]
+//   A column j: row j; for a state column of frame k >= 1 the +1 of s_k in g_{k-1}[c]; for k < N-1 the nx rows of g_k
+inline void sm_build_pattern(int nx, int nu, int N, std::vector<int> &Pp, std::vector<int> &Pi, std::vector<int> &Ap, std::vector<int> &Ai) {
+  const int f = nx + nu, np = nx, n = np + N * f;
+  Pp.assign(1, 0); Ap.assign(1, 0); Pi.clear(); Ai.clear();
+  for (int i = 0; i < np; i++) {
+    Pi.push_back(i);
+    for (int k = 0; k < N; k++) Pi.push_back(np + k * f + i);
+    Pp.push_back((int)Pi.size());
+    Ai.push_back(i); Ap.push_back((int)Ai.size());
+  }
+  for (int k = 0; k < N; k++)
+    for (int c = 0; c < f; c++) {
+      const int j = np + k * f + c;
+      if (c < nx) Pi.push_back(c);
+      Pi.push_back(j);
+      Pp.push_back((int)Pi.size());
+      Ai.push_back(j);
+      if (k >= 1 && c < nx) Ai.push_back(n + (k - 1) * nx + c);
+      if (k < N - 1) for (int r = 0; r < nx; r++) Ai.push_back(n + k * nx + r);
+      Ap.push_back((int)Ai.size());
+    }
+}

@@ -87,3 +87,79 @@ class SQPOptimizationSolver:
                 if normDelta < 1e-6:
                     break
         return {"x": self.result_["x"].copy(), "f": self.result_["f"].copy()}
+
+
+class DeviceSQPOptimizationSolver:
+    """The same outer loop with every step on the GPU: local-system evaluation
+    (mpcqp_stage_eval, replaces getLocalSystem :100-120), QP (mpcqp_update on borrowed device arrays + mpcqp_solve), damped
+    update (mpcqp_stage_step, :171-177) and objective (mpcqp_stage_merit, :180-181).  The iterate, bounds and QP data never
+    visit the host; only the returned x / f do.  For the stage-OCP zoo models (models.StageOCP subclasses)."""
+
+    def __init__(self, nlp, options, batch=1, device=-1):
+        import torch
+        from .batch_qp import BatchQP
+        from .stage_eval import StageEvaluator
+        self.model = nlp
+        self.stepNum_ = int(options["max_iter"])
+        self.alpha_ = float(options["alpha"])
+        self.verbose_ = bool(options.get("verbose", False))
+        self.warm_start_admm = bool(options.get("warm_start_admm", False))
+        self.batch = int(batch)
+        self.ev = StageEvaluator(nlp, device=device)
+        # reference SQPOptimizationSolver.cpp:80-85
+        self.qp = BatchQP(self.ev.n, self.ev.m, self.batch, self.ev.Pp, self.ev.Pi, self.ev.Ap, self.ev.Ai,
+                          eps_abs=1e-3, eps_rel=1e-3, max_iter=10000, warm_start=1 if self.warm_start_admm else 0, device=device)
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        mk = lambda w, dt=torch.float64: torch.zeros((self.batch, w), dtype=dt, device=self.dev)
+        self.x = mk(self.ev.nvar)                        # persists across calls like result_ (:88-91)
+        self.ls = self.ev.alloc(self.batch, self.dev)
+        self.dw = mk(self.ev.n); self.y = mk(self.ev.m)
+        self.status = torch.zeros(self.batch, dtype=torch.int32, device=self.dev)
+        self.iters = torch.zeros(self.batch, dtype=torch.int32, device=self.dev)
+        self.admm_iterations = []
+        self.f = None; self.gmax = None
+        self._have_start = False                         # like last_qp_info of the host loop: survives across calls
+
+    def _dev(self, a, w):
+        import torch
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.dev, torch.float64)
+        else:
+            t = torch.as_tensor(np.asarray(a, float), dtype=torch.float64, device=self.dev)
+        t = t.reshape(-1, w) if w else t.reshape(-1, 0)
+        return t.expand(self.batch, w).contiguous()
+
+    def getOptimalSolution(self, arg, to_host=True):
+        import torch
+        ev = self.ev
+        p = self._dev(arg.get("p", np.zeros(ev.np)), ev.np)
+        lbx = self._dev(arg["lbx"], ev.nvar); ubx = self._dev(arg["ubx"], ev.nvar)
+        lbg = self._dev(arg["lbg"], ev.ng); ubg = self._dev(arg["ubg"], ev.ng)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        for i in range(self.stepNum_):
+            ev.eval(p, self.x, lbx, ubx, lbg, ubg, out=self.ls, stream=stream)
+            self.qp.update(self.ls["P"], self.ls["q"], self.ls["A"], self.ls["l"], self.ls["u"])
+            if self.warm_start_admm:
+                if self._have_start:
+                    # after x += alpha * dx the remaining step is (1 - alpha) * dx; duals carry over
+                    self.dw.mul_(1.0 - self.alpha_)
+                else:
+                    self.dw.zero_(); self.y.zero_()
+                self.qp.warm_start(self.dw, self.y)
+            self.qp.solve(stream)
+            self.qp.get_device(x=self.dw, y=self.y, status=self.status, iters=self.iters)
+            self._have_start = True
+            step = ev.step(self.alpha_, self.dw, self.x, stream=stream)
+            self.f, self.gmax = ev.merit(p, self.x, stream=stream)
+            self.admm_iterations.append(self.iters.clone())
+            if self.verbose_:
+                normDelta = float(step.max())
+                print("SQP iter %d/%d  max|dx| %.3e  f[0] %.6g" % (i + 1, self.stepNum_, normDelta, float(self.f[0])))
+                if normDelta < 1e-6:
+                    break
+        if not to_host:
+            return {"x": self.x, "f": self.f}
+        return {"x": self.x.cpu().numpy(), "f": self.f.cpu().numpy()}
+
+    def close(self):
+        self.qp.close(); self.ev.close()
