@@ -47,6 +47,11 @@ class SQPOptimizationSolver:
         self.verbose_ = bool(verbose)
         self.qpSolver_.setVerbosity(verbose)
 
+    def setInitialGuess(self, x):
+        """extension: the reference ignores arg["x0"] and starts from zero (:88-91); this overwrites the stored iterate"""
+        self.result_["x"] = np.array(np.broadcast_to(np.asarray(x, float).reshape(-1, self.result_["x"].shape[1]), self.result_["x"].shape))
+        self.last_qp_info = None
+
     def getLocalSystem(self, arg):
         B = self.batch
         as2d = lambda a, w: np.broadcast_to(np.asarray(a, float).reshape(-1, w) if w else np.zeros((1, 0)), (B, w))
@@ -119,6 +124,11 @@ class DeviceSQPOptimizationSolver:
         self.admm_iterations = []
         self.f = None; self.gmax = None
         self._have_start = False                         # like last_qp_info of the host loop: survives across calls
+
+    def setInitialGuess(self, x):
+        """extension: the reference ignores arg["x0"] and starts from zero (:88-91); this overwrites the stored iterate"""
+        self.x.copy_(self._dev(x, self.ev.nvar))
+        self._have_start = False
 
     def _dev(self, a, w):
         import torch

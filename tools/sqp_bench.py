@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Device-resident SQP tick (BASELINE config 4 shape): per SQP iteration
+mpcqp_stage_eval -> mpcqp_update(device) -> mpcqp_solve -> mpcqp_stage_step/merit, nothing crosses PCIe.
+usage: python tools/sqp_bench.py [workload] [horizon] [batch] [sqp_iters] [alpha] [warm 0|1] [host_batch]
+Prints one JSON line: kernel times from CUDA events on the launch stream, the host loop (NumPy local system + H2D) for
+comparison on `host_batch` instances."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from optimal_control_problem_amd import models
+from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cartpole"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+alpha = float(sys.argv[5]) if len(sys.argv) > 5 else 0.5
+warm = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
+HB = int(sys.argv[7]) if len(sys.argv) > 7 else 1024
+
+mdl, ls, meta = models.make_workload(name, B, N=N)
+arg = {k: torch.as_tensor(meta[k], dtype=torch.float64, device="cuda") for k in ("lbx", "ubx", "lbg", "ubg", "p")}
+opt = {"max_iter": iters, "alpha": alpha, "warm_start_admm": warm}
+
+dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B)
+dev.setInitialGuess(meta["x_iterate"])                      # start from the seeded iterate, not the reference's x = 0
+dev.getOptimalSolution(arg, to_host=False)                  # warm-up (first launches, allocator)
+dev.setInitialGuess(meta["x_iterate"]); dev.admm_iterations = []
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = dev.getOptimalSolution(arg, to_host=False)
+torch.cuda.synchronize()
+t_dev = time.perf_counter() - t0
+admm = torch.stack(dev.admm_iterations).double().mean(dim=1).cpu().numpy()
+
+# kernel-level split of one iteration at the final iterate
+ev, qp = dev.ev, dev.qp
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+pt = arg["p"]
+e0.record()
+for _ in range(10):
+    ev.eval(pt, dev.x, arg["lbx"], arg["ubx"], arg["lbg"], arg["ubg"], out=dev.ls)
+e1.record(); torch.cuda.synchronize()
+eval_ms = e0.elapsed_time(e1) / 10
+e0.record()
+for _ in range(10):
+    ev.merit(pt, dev.x); ev.step(0.0, dev.dw, dev.x)
+e1.record(); torch.cuda.synchronize()
+aux_ms = e0.elapsed_time(e1) / 10
+bytes_eval = 8.0 * B * (ev.np + 3 * ev.nvar + 2 * ev.ng + ev.nnzP + ev.n + ev.nnzA + 2 * ev.m)
+
+# host loop on a sample
+hmdl, hls, hmeta = models.make_workload(name, HB, N=N)
+harg = dict(lbx=hmeta["lbx"], ubx=hmeta["ubx"], lbg=hmeta["lbg"], ubg=hmeta["ubg"], p=hmeta["p"])
+host = SQPOptimizationSolver(hmdl, opt, batch=HB)
+host.setInitialGuess(hmeta["x_iterate"])
+t0 = time.perf_counter(); rh = host.getOptimalSolution(harg); t_host = time.perf_counter() - t0
+out = {
+    "workload": "%s N=%d batch=%d, %d SQP iterations alpha=%g, ADMM warm start %s" % (name, N, B, iters, alpha, warm),
+    "device_loop_s": t_dev, "sqp_ticks_per_s": B / t_dev, "qp_solves_per_s": B * iters / t_dev,
+    "mean_admm_iters_per_sqp_iter": [round(float(v), 1) for v in admm],
+    "eval_kernel_ms": eval_ms, "eval_GBps": bytes_eval / eval_ms / 1e6, "merit_step_ms": aux_ms,
+    "final_objective_mean": float(res["f"].mean()), "final_dynamics_violation_max": float(dev.gmax.max()),
+    "qp_status_counts_last_iter": {int(k): int(v) for k, v in zip(*np.unique(dev.status.cpu().numpy(), return_counts=True))},
+    "host_loop": {"batch": HB, "s": t_host, "sqp_ticks_per_s": HB / t_host, "local_system_ms": host.timings["local_system_ms"],
+                  "qp_ms_incl_h2d": host.timings["qp_ms"]},
+}
+print(json.dumps(out))
