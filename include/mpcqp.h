@@ -90,6 +90,12 @@ int mpcqp_update(mpcqp_handle *h,
  * x0 [batch*n], y0 [batch*m]; honoured by the next solve when settings.warm_start != 0. */
 int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int mem);
 
+/* Per-instance starting rho for the following solves (rho0 [batch]; entries <= 0 mean settings.rho; NULL returns to
+ * settings.rho for all).  A kept OSQP workspace carries its adapted rho from one problem to the next
+ * (osqp_update_* do not reset it) -- the behaviour the reference's unused update* members would have had
+ * (CuCaQP.cpp:106-161); feed info[3] of the previous solve back in. */
+int mpcqp_set_rho(mpcqp_handle *h, const double *rho0, int mem);
+
 /* Replaces CuCaQP::initSolver + CuCaQP::solve (CuCaQP.cpp:183-211): per QP, Ruiz scaling, KKT
  * factorisation and the ADMM loop run in one launch on `stream` (a hipStream_t, NULL = default stream).
  * Asynchronous: returns after the launch; results are ordered on `stream`. */
@@ -175,8 +181,11 @@ int mpcqp_stage_eval(mpcqp_stage *s, int batch, const double *p, const double *x
  * (either may be NULL) at iterate x; device pointers */
 int mpcqp_stage_merit(mpcqp_stage *s, int batch, const double *p, const double *x, double *f, double *gmax, void *stream);
 /* the damped update result.x += alpha * solution[pSize:] (SQPOptimizationSolver.cpp:171-177): x [batch*nvar] +=
- * alpha * dw[b*n + np ...]; device pointers.  step_max [batch] (may be NULL) receives max|alpha * dx| per instance. */
-int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max, void *stream);
+ * alpha * dw[b*n + np ...]; device pointers.  step_max [batch] (may be NULL) receives max|alpha * dx| per instance.
+ * status [batch] (may be NULL = the reference's behaviour: every step is taken, NaN from an infeasible QP included):
+ * when given, instances whose QP status is not MPCQP_SOLVED / _SOLVED_INACCURATE / _MAX_ITER_REACHED keep their x. */
+int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max,
+                     const int *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,23 @@ class BatchQP:
         self._keep_ws = (kx, ky)
         _lib.check(_lib.lib().mpcqp_warm_start(self._h, px, py, memx))
 
+    def set_rho(self, rho0):
+        """per-instance starting rho [batch] (NumPy or CUDA tensor), None = settings.rho"""
+        if rho0 is None:
+            self._keep_rho = None
+            _lib.check(_lib.lib().mpcqp_set_rho(self._h, None, _lib.MEM_HOST))
+            return
+        if _is_torch(rho0):
+            import torch
+            if rho0.dtype != torch.float64 or not rho0.is_contiguous() or tuple(rho0.shape) != (self.batch,):
+                raise ValueError("rho0: expected a contiguous float64 tensor of %d values" % self.batch)
+            self._keep_rho = rho0
+            _lib.check(_lib.lib().mpcqp_set_rho(self._h, rho0.data_ptr(), _lib.MEM_DEVICE if rho0.is_cuda else _lib.MEM_HOST))
+        else:
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(rho0, dtype=np.float64), (self.batch,)))
+            self._keep_rho = a
+            _lib.check(_lib.lib().mpcqp_set_rho(self._h, a.ctypes.data, _lib.MEM_HOST))
+
     def solve(self, stream=None):
         _lib.check(_lib.lib().mpcqp_solve(self._h, stream))
 

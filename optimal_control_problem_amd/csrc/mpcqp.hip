@@ -53,7 +53,7 @@ struct DevPlan {
 };
 struct DevIO {
   const double *P, *q, *A, *l, *u; long sP, sq, sA, sl, su;
-  const double *x0, *y0;
+  const double *x0, *y0, *rho0;
   double *x, *y, *z; int *status, *iters; double *info;
   double *ws; double *cscale; long long *dbg;
 };
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, cons
     ell_rows(pl.A, valA, cx.X, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
     wsync();
   }
-  cx.rho = fmin(fmax(st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  cx.rho = fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
   int status = MPCQP_UNSOLVED, iter_done = 0;
   Info in; memset(&in, 0, sizeof(in));
   bool ok = factorize(cx);
@@ -1225,7 +1225,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
     bsync<NW>();
   }
-  cx.rho = fmin(fmax(st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  cx.rho = fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
   int status = MPCQP_UNSOLVED, iter_done = 0;
   Info in; memset(&in, 0, sizeof(in));
   TS(2);
@@ -1376,7 +1376,7 @@ struct mpcqp_handle {
   std::vector<void *> dev_allocs;
   double *ws = nullptr;
   double *dP = nullptr, *dq = nullptr, *dA = nullptr, *dl = nullptr, *du = nullptr;  // owned copies (host-memory updates)
-  double *dx0 = nullptr, *dy0 = nullptr;
+  double *dx0 = nullptr, *dy0 = nullptr, *drho0 = nullptr;
   double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
@@ -1501,6 +1501,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       h->occ4 = h->gblocks && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
+      if (const char *pad = getenv("MPCQP_LDS_MIN")) h->lds = std::max<long>(h->lds, atol(pad));   // experiment: limit workgroups per CU
     }
     h->variant = want;
   }
@@ -1602,6 +1603,19 @@ int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int me
   HIPCHK(hipMemcpy(h->dx0, x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->dy0, y0, (size_t)h->batch * h->m * sizeof(double), hipMemcpyHostToDevice));
   h->io.x0 = h->dx0; h->io.y0 = h->dy0;
+  return MPCQP_OK;
+}
+
+int mpcqp_set_rho(mpcqp_handle *h, const double *rho0, int mem) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (!rho0) { h->io.rho0 = nullptr; return MPCQP_OK; }
+  if (mem == MPCQP_MEM_DEVICE) { h->io.rho0 = rho0; return MPCQP_OK; }
+  if (mem != MPCQP_MEM_HOST) return fail(MPCQP_ERR_ARG, "mem must be MPCQP_MEM_HOST or MPCQP_MEM_DEVICE");
+  int rc;
+  if (!h->drho0) { if ((rc = dalloc(h, &h->drho0, (size_t)h->batch))) return rc; }
+  HIPCHK(hipMemcpy(h->drho0, rho0, (size_t)h->batch * sizeof(double), hipMemcpyHostToDevice));
+  h->io.rho0 = h->drho0;
   return MPCQP_OK;
 }
 

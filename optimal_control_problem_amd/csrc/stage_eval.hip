@@ -121,10 +121,14 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
 }
 
 __global__ void __launch_bounds__(256) stage_step_kernel(int batch, int nvar, int n, int np, double alpha, const double *__restrict__ dw,
-                                                         double *__restrict__ x, double *__restrict__ step_max) {
+                                                         double *__restrict__ x, double *__restrict__ step_max, const int *__restrict__ status) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= batch) return;
   double mx = 0.0;
+  if (status) {
+    const int s = status[b];
+    if (s != MPCQP_SOLVED && s != MPCQP_SOLVED_INACCURATE && s != MPCQP_MAX_ITER_REACHED) { if (step_max && lane == 0) step_max[b] = 0.0; return; }
+  }
   for (int i = lane; i < nvar; i += 64) {
     const double d = alpha * dw[(long)b * n + np + i];
     x[(long)b * nvar + i] += d; mx = fmax(mx, fabs(d));
@@ -253,12 +257,12 @@ int mpcqp_stage_merit(mpcqp_stage *s, int batch, const double *p, const double *
   return MPCQP_OK;
 }
 
-int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max, void *stream) {
+int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max, const int *status, void *stream) {
   if (!s) return mpcqp_set_error(MPCQP_ERR_ARG, "stage handle is null");
   if (batch <= 0 || !dw || !x) return mpcqp_set_error(MPCQP_ERR_ARG, "bad batch or null data pointer");
   MPCQP_HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  stage_step_kernel<<<(unsigned)((batch + 3) / 4), 256, 0, st>>>(batch, s->sd.nvar, s->sd.n, s->sd.np, alpha, dw, x, step_max);
+  stage_step_kernel<<<(unsigned)((batch + 3) / 4), 256, 0, st>>>(batch, s->sd.nvar, s->sd.n, s->sd.np, alpha, dw, x, step_max, status);
   MPCQP_HIPCHK(hipGetLastError());
   return MPCQP_OK;
 }

@@ -37,6 +37,7 @@ class CuCaQP:
         self._pattern_key = None
         self._result = None
         self._start = None
+        self._rho0 = None
 
     # -- dimensions (CuCaQP.cpp:23-41)
     def setDimension(self, numOfVariables, numOfConstraints):
@@ -74,6 +75,11 @@ class CuCaQP:
         self._start = (np.ascontiguousarray(x0, dtype=np.float64).reshape(self.batch, -1),
                        np.ascontiguousarray(y0, dtype=np.float64).reshape(self.batch, -1))
         self._kw["warm_start"] = 1
+
+    def setRhoStart(self, rho0):
+        """extension: per-instance starting rho for the next solves (a kept OSQP workspace carries its adapted rho over);
+        None returns to the configured rho"""
+        self._rho0 = None if rho0 is None else np.ascontiguousarray(np.broadcast_to(np.asarray(rho0, np.float64), (self.batch,)))
 
     def setSolverSetting(self, **kw):
         """extension: any field of mpcqp_settings (rho, sigma, alpha, scaling, adaptive_rho, ...)"""
@@ -173,6 +179,7 @@ class CuCaQP:
             self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
             if self._start is not None:
                 self._qp.warm_start(self._start[0], self._start[1])
+            self._qp.set_rho(self._rho0)
         except (_lib.MpcqpError, ValueError) as e:
             return _err("Failed to initialize solver. (%s)" % e)
         self.isInitialized_ = True

@@ -41,6 +41,8 @@ class SQPOptimizationSolver:
         # extension (BASELINE config 4): warm-start each QP's ADMM from the previous SQP
         # iteration's solution.  Off by default: the reference cold-starts every QP (CuCaQP.cpp:271-288).
         self.warm_start_admm = bool(options.get("warm_start_admm", False))
+        # and carry each instance's adapted rho into its next QP, as a kept OSQP workspace would (with warm_start_admm)
+        self.carry_rho = bool(options.get("carry_rho", False))
         self.admm_iterations = []
 
     def setVerbose(self, verbose):
@@ -74,6 +76,8 @@ class SQPOptimizationSolver:
                 if info is not None and np.isfinite(info["x"]).all() and np.isfinite(info["y"]).all():
                     # after the damped update x += alpha * dx the remaining step is (1 - alpha) * dx; duals carry over
                     self.qpSolver_.setPrimalDualStart((1.0 - self.alpha_) * info["x"], info["y"])
+                    if self.carry_rho and hasattr(self.qpSolver_, "setRhoStart"):
+                        self.qpSolver_.setRhoStart(info["rho"])
             self.qpSolver_.initSolver()
             self.qpSolver_.solve()
             t2 = time.perf_counter()
@@ -109,6 +113,9 @@ class DeviceSQPOptimizationSolver:
         self.alpha_ = float(options["alpha"])
         self.verbose_ = bool(options.get("verbose", False))
         self.warm_start_admm = bool(options.get("warm_start_admm", False))
+        self.carry_rho = bool(options.get("carry_rho", False))
+        # extension: an instance whose QP is infeasible keeps its iterate (the reference adds the NaN solution, :171-177)
+        self.skip_failed_steps = bool(options.get("skip_failed_steps", False))
         self.batch = int(batch)
         self.ev = StageEvaluator(nlp, device=device)
         # reference SQPOptimizationSolver.cpp:80-85
@@ -121,6 +128,7 @@ class DeviceSQPOptimizationSolver:
         self.dw = mk(self.ev.n); self.y = mk(self.ev.m)
         self.status = torch.zeros(self.batch, dtype=torch.int32, device=self.dev)
         self.iters = torch.zeros(self.batch, dtype=torch.int32, device=self.dev)
+        self.info = mk(4); self.rho = torch.zeros(self.batch, dtype=torch.float64, device=self.dev)
         self.admm_iterations = []
         self.f = None; self.gmax = None
         self._have_start = False                         # like last_qp_info of the host loop: survives across calls
@@ -153,13 +161,18 @@ class DeviceSQPOptimizationSolver:
                 if self._have_start:
                     # after x += alpha * dx the remaining step is (1 - alpha) * dx; duals carry over
                     self.dw.mul_(1.0 - self.alpha_)
+                    if self.skip_failed_steps:               # an infeasible QP returns NaN: restart that instance cold
+                        torch.nan_to_num_(self.dw, nan=0.0); torch.nan_to_num_(self.y, nan=0.0)
+                    if self.carry_rho:
+                        self.rho.copy_(self.info[:, 3]); self.qp.set_rho(self.rho)
                 else:
                     self.dw.zero_(); self.y.zero_()
+                    self.qp.set_rho(None)
                 self.qp.warm_start(self.dw, self.y)
             self.qp.solve(stream)
-            self.qp.get_device(x=self.dw, y=self.y, status=self.status, iters=self.iters)
+            self.qp.get_device(x=self.dw, y=self.y, status=self.status, iters=self.iters, info=self.info)
             self._have_start = True
-            step = ev.step(self.alpha_, self.dw, self.x, stream=stream)
+            step = ev.step(self.alpha_, self.dw, self.x, stream=stream, status=self.status if self.skip_failed_steps else None)
             self.f, self.gmax = ev.merit(p, self.x, stream=stream)
             self.admm_iterations.append(self.iters.clone())
             if self.verbose_:

@@ -30,7 +30,7 @@ def _bind(L):
     L.mpcqp_stage_pattern.argtypes = [vp, vp, vp, vp, vp]
     L.mpcqp_stage_eval.argtypes = [vp, C.c_int] + [dp] * 11 + [vp]
     L.mpcqp_stage_merit.argtypes = [vp, C.c_int, dp, dp, dp, dp, vp]
-    L.mpcqp_stage_step.argtypes = [vp, C.c_int, C.c_double, dp, dp, dp, vp]
+    L.mpcqp_stage_step.argtypes = [vp, C.c_int, C.c_double, dp, dp, dp, vp, vp]
     L._stage_bound = True
     return L
 
@@ -117,11 +117,12 @@ class StageEvaluator:
                                                 f.data_ptr(), g.data_ptr(), stream))
         return f, g
 
-    def step(self, alpha, dw, x, stream=None):
-        """x += alpha * dw[:, np:] in place; returns max|alpha dx| per instance"""
+    def step(self, alpha, dw, x, stream=None, status=None):
+        """x += alpha * dw[:, np:] in place; returns max|alpha dx| per instance.  status (int32 CUDA tensor [B], optional):
+        instances whose QP did not return a point keep their x"""
         import torch
         B = x.shape[0]
         sm = torch.empty(B, dtype=torch.float64, device=x.device)
         _lib.check(_lib.lib().mpcqp_stage_step(self._h, B, float(alpha), _check(dw, (B, self.n), "dw"), _check(x, (B, self.nvar), "x"),
-                                               sm.data_ptr(), stream))
+                                               sm.data_ptr(), None if status is None else status.data_ptr(), stream))
         return sm

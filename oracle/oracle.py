@@ -49,6 +49,9 @@ def lib():
         L.orc_solve_batch.restype = C.c_int
         L.orc_solve_batch.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int] + \
             [C.c_void_p, C.c_long] * 5 + [C.c_void_p] * 8 + [C.c_int]
+        L.orc_solve_batch_rho.restype = C.c_int
+        L.orc_solve_batch_rho.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int] + \
+            [C.c_void_p, C.c_long] * 5 + [C.c_void_p] * 9 + [C.c_int]
         _LIB = L
     return _LIB
 
@@ -85,7 +88,7 @@ class Pattern:
     def nnzL(self):
         return lib().orc_pattern_kkt_nnzL(self.h)
 
-    def solve(self, Px, q, Ax, l, u, settings=None, x0=None, y0=None, nthreads=1):
+    def solve(self, Px, q, Ax, l, u, settings=None, x0=None, y0=None, nthreads=1, rho0=None):
         """Px [B,nnzP] or [nnzP] (shared); q [B,n]; Ax [B,nnzA] or [nnzA]; l,u [B,m].  Returns dict."""
         s = settings or default_settings()
         q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float64)
@@ -108,8 +111,10 @@ class Pattern:
         if x0 is not None:
             x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n)
             y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m)
-        rc = lib().orc_solve_batch(self.h, C.byref(s), B, _p(Px), sP, _p(q), self.n, _p(Ax), sA, _p(l), sl, _p(u), su,
-                                   _p(x0), _p(y0), _p(x), _p(y), _p(z), _p(status), _p(iters), _p(info), int(nthreads))
+        if rho0 is not None:
+            rho0 = np.ascontiguousarray(np.broadcast_to(np.asarray(rho0, dtype=np.float64), (B,)))
+        rc = lib().orc_solve_batch_rho(self.h, C.byref(s), B, _p(Px), sP, _p(q), self.n, _p(Ax), sA, _p(l), sl, _p(u), su,
+                                       _p(x0), _p(y0), _p(rho0), _p(x), _p(y), _p(z), _p(status), _p(iters), _p(info), int(nthreads))
         if rc != 0:
             raise RuntimeError("orc_solve_batch failed rc=%d" % rc)
         return dict(x=x, y=y, z=z, status=status, iters=iters, obj=info[:, 0], prim_res=info[:, 1],

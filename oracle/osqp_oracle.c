@@ -501,7 +501,7 @@ static double rho_estimate(work_t *w) {
 }
 
 static void solve_one(work_t *w, const double *Px, const double *q, const double *Ax, const double *l, const double *u,
-                      const double *x0, const double *y0) {
+                      const double *x0, const double *y0, double rho_start) {
   const orc_pattern *pt = w->pt; const orc_settings *st = w->st; int n = w->n, m = w->m;
   /* [S1] load; clip bounds to +-OSQP_INFTY as osqp_setup does */
   for (int k = 0; k < pt->nnzP; k++) w->P[k] = Px[pt->Pmap[k]];
@@ -511,7 +511,7 @@ static void solve_one(work_t *w, const double *Px, const double *q, const double
   w->c = w->cinv = 1.0;
   if (st->scaling) scale_data(w);
   else { for (int j = 0; j < n; j++) w->D[j] = w->Dinv[j] = 1.0; for (int i = 0; i < m; i++) w->E[i] = w->Einv[i] = 1.0; }
-  w->rho = st->rho;
+  w->rho = rho_start > 0.0 ? rho_start : st->rho;   /* a kept workspace carries rho over (osqp_update_* leave it alone) */
   set_rho_vec(w, 1);
   w->status = ORC_UNSOLVED; w->iter = 0; w->prim_res = w->dual_res = w->obj = 0.0;
   for (int j = 0; j < n; j++) w->x[j] = w->xprev[j] = w->dx[j] = 0.0;
@@ -600,6 +600,14 @@ int orc_solve_batch(const orc_pattern *pt, const orc_settings *st, int batch,
                     const double *l, long sl, const double *u, long su,
                     const double *x0, const double *y0,
                     double *x, double *y, double *z, int *status, int *iters, double *info, int nthreads) {
+  return orc_solve_batch_rho(pt, st, batch, Px, sP, q, sq, Ax, sA, l, sl, u, su, x0, y0, NULL, x, y, z, status, iters, info, nthreads);
+}
+
+int orc_solve_batch_rho(const orc_pattern *pt, const orc_settings *st, int batch,
+                        const double *Px, long sP, const double *q, long sq, const double *Ax, long sA,
+                        const double *l, long sl, const double *u, long su,
+                        const double *x0, const double *y0, const double *rho0,
+                        double *x, double *y, double *z, int *status, int *iters, double *info, int nthreads) {
   if (!pt || !st || batch < 0) return 1;
   if (nthreads < 1) nthreads = 1;
 #ifdef _OPENMP
@@ -612,7 +620,7 @@ int orc_solve_batch(const orc_pattern *pt, const orc_settings *st, int batch,
 #endif
     for (int b = 0; b < batch; b++) {
       solve_one(w, Px + (size_t)b * sP, q + (size_t)b * sq, Ax + (size_t)b * sA, l + (size_t)b * sl, u + (size_t)b * su,
-                x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL);
+                x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, rho0 ? rho0[b] : 0.0);
       store(w, b, x, y, z, status, iters, info);
     }
     work_free(w);

@@ -93,6 +93,16 @@ int orc_solve_batch(const orc_pattern *pat, const orc_settings *settings, int ba
                     const double *x0, const double *y0,
                     double *x, double *y, double *z, int *status, int *iters, double *info,
                     int nthreads);
+/* same, with a per-instance starting rho (rho0 [batch], entries <= 0 or rho0 == NULL mean settings->rho): what a kept
+ * OSQP workspace does across osqp_update_* calls -- the fast path the reference's unused CuCaQP::update* members
+ * (reference src/sqp_solver/CuCaQP.cpp:106-161) were written for */
+int orc_solve_batch_rho(const orc_pattern *pat, const orc_settings *settings, int batch,
+                        const double *Px, long strideP, const double *q, long strideq,
+                        const double *Ax, long strideA, const double *l, long stridel,
+                        const double *u, long strideu,
+                        const double *x0, const double *y0, const double *rho0,
+                        double *x, double *y, double *z, int *status, int *iters, double *info,
+                        int nthreads);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,30 @@ def test_warm_start(built):
     _close(got, ref, "x")
 
 
+@pytest.mark.parametrize("name,B,N", [("cartpole", 24, 30), ("quadrotor", 8, 10)])
+def test_starting_rho_per_instance(built, name, B, N):
+    """mpcqp_set_rho: per-instance starting rho (what a kept OSQP workspace carries over) against the oracle, host and
+    device pointers, mixed with entries <= 0 that fall back to settings.rho; NULL restores the default"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    cold = problems.oracle_solve(ls)
+    rho0 = cold["rho"].copy(); rho0[::3] = 0.0; rho0[1::3] *= 7.0
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    ref = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings(), rho0=rho0)
+    assert (ref["iters"][::3] == cold["iters"][::3]).all()
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.set_rho(rho0); qp.solve(); got = qp.get()
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    _close(got, ref, "x"); _close(got, ref, "y")
+    import torch
+    qp.set_rho(torch.as_tensor(rho0, device="cuda")); qp.solve(); dev = qp.get()
+    assert np.array_equal(dev["x"], got["x"]) and np.array_equal(dev["iters"], got["iters"])
+    qp.set_rho(None); qp.solve(); again = qp.get(); qp.close()
+    assert (again["iters"] == cold["iters"]).all()
+    _close(again, cold, "x")
+
+
 def test_error_behaviour(built):
     """bool/err-code behaviour mirroring CuCaQP's checks (reference src/sqp_solver/CuCaQP.cpp:23-27,49-52,199-203)."""
     from optimal_control_problem_amd import _lib

@@ -53,6 +53,11 @@ def test_eval_matches_host(built, name, N, B):
     sm = ev.step(0.5, _dev(dw), x)
     assert np.array_equal(x.cpu().numpy(), meta["x_iterate"] + 0.5 * dw[:, mdl.np:])
     assert np.array_equal(sm.cpu().numpy(), np.abs(0.5 * dw[:, mdl.np:]).max(axis=1))
+    # with a status array, instances whose QP returned no point keep their iterate
+    status = torch.ones(B, dtype=torch.int32, device="cuda"); status[0] = 3; status[B - 1] = 9; status[1] = 2; status[2] = 7
+    before = x.clone(); sm = ev.step(1.0, _dev(dw), x, status=status)
+    moved = (x != before).any(dim=1).cpu().numpy()
+    assert not moved[0] and not moved[B - 1] and moved[1:B - 1].all() and float(sm[0]) == 0.0
     ev.close()
 
 
