@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
     ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4"])
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 flow on a one-GPU box: all ranks use cuda:0, collectives over gloo")
     ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
     args = ap.parse_args()
 
@@ -78,7 +79,9 @@ def main():
     from optimal_control_problem_amd import models, sharding
     from optimal_control_problem_amd.batch_qp import BatchQP
 
-    rank, world, local, dist = sharding.init_distributed(args.gpus)
+    rank, world, local, dist = sharding.init_distributed(args.gpus, backend="gloo" if args.share_gpu else None)
+    if args.share_gpu:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)

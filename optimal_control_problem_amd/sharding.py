@@ -39,7 +39,12 @@ def _dev(dist):
 
 
 def barrier(dist):
-    if dist is not None:
+    if dist is None:
+        return
+    if dist.get_backend() == "nccl":
+        import torch
+        dist.barrier(device_ids=[torch.cuda.current_device()])     # name the device: no guessing, no hang on a wrong one
+    else:
         dist.barrier()
 
 
