@@ -1485,11 +1485,18 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // measured on MI355X: one wave per QP with the factor in LDS when it is tiny; four waves per QP
       // with the factor in LDS when at least two QPs fit per CU; otherwise occupancy beats residency and the factor
       // blocks are streamed from the HBM slab by the same LDL' / segment machinery (several workgroups per CU)
-      ResPlan r1 = build_res_plan(p1, 1);
-      if (small_ok && lds_bytes_res(p1, r1) <= 40 * 1024) want = 1;
+      ResPlan r1 = build_res_plan(p1, 1), r4 = build_res_plan(p4, 4);
+      const long l1 = lds_bytes_res(p1, r1), l4 = lds_bytes_res(p4, r4);
+      // latency regime (measured, tools/graph_tick.py): when the whole batch is resident in one round of 4-wave workgroups
+      // (two per CU by registers, one when the factor needs more than half the LDS), four waves per QP with the factor in
+      // LDS finish a QP soonest (double integrator x256: 1.12 ms vs 1.41 ms with one wave per QP; quadrotor N=20 x256:
+      // 1.21 ms vs 1.96 ms with the factor streamed from HBM)
+      const long cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      const long cap4 = (small_ok && l4 <= LDS_MAX) ? std::min<long>(LDS_MAX / l4, 2) : 0;
+      if (cap4 > 0 && (long)batch <= cus * cap4) want = 4;
+      else if (small_ok && l1 <= 40 * 1024) want = 1;
       else {
-        ResPlan r4 = build_res_plan(p4, 4);
-        if (small_ok && lds_bytes_res(p4, r4) <= 80 * 1024) want = 4;
+        if (small_ok && l4 <= 80 * 1024) want = 4;
         else if (small_ok && lds_bytes_res_gb(p4, r4) <= LDS_MAX) { want = 4; h->gblocks = true; }
         else want = 0;
       }
