@@ -148,6 +148,7 @@ int mpcqp_debug_blockops(const double *A, const double *B, const double *C, cons
 #define MPCQP_MODEL_DOUBLE_INTEGRATOR 0   /* nx 2, nu 1, exact discrete map; no parameters                       */
 #define MPCQP_MODEL_QUADROTOR 1           /* nx 12, nu 4, RK4; par = {mass, grav, arm, kappa, Jx, Jy, Jz}        */
 #define MPCQP_MODEL_CARTPOLE 2            /* nx 4, nu 1, RK4; par = {m_cart, m_pole, length, grav}               */
+#define MPCQP_MODEL_USER 3                /* dynamics from a generated library, see mpcqp_stage_create_user       */
 
 typedef struct mpcqp_stage_desc {
   int model;        /* MPCQP_MODEL_*            */
@@ -165,6 +166,13 @@ typedef struct mpcqp_stage mpcqp_stage;
 int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d);
 /* the once-per-problem part (the reference's constructor builds the symbolic function once, SQPOptimizationSolver.cpp:12-92) */
 int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out);
+/* User-defined dynamics: the native form of the reference's gen_code / load_lib flow (solver_settings.gen_code writes the
+ * CasADi function out as C, gcc builds a shared library, load_lib loads it; reference src/OptimalControlProblem.cpp:263-287,
+ * 602-640).  `library_path` is a shared library generated by optimal_control_problem_amd/codegen.py from a traced discrete
+ * map s_{k+1} = F(s_k, u_k): a scalar-generic functor instantiated into the same evaluation kernels (hipcc, gfx950), exporting
+ * mpcqp_user_abi / _dims / _eval / _merit.  d->model and d->par are ignored (constants are baked into the generated code);
+ * nx <= 16, nu <= 8. */
+int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path, mpcqp_stage **out);
 void mpcqp_stage_destroy(mpcqp_stage *s);
 /* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
 int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);

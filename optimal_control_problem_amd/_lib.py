@@ -17,7 +17,7 @@ STATUS = {1: "solved", 2: "solved_inaccurate", 3: "primal_infeasible", 4: "prima
 EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_update", "mpcqp_warm_start", "mpcqp_set_rho", "mpcqp_solve",
            "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms",
            "mpcqp_plan_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
-           "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_destroy", "mpcqp_stage_dims", "mpcqp_stage_pattern",
+           "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_dims", "mpcqp_stage_pattern",
            "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step"]
 
 
@@ -40,7 +40,7 @@ class MpcqpError(RuntimeError):
 def build(force=False):
     """Compile libmpcqp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "plan.hpp", "stage_eval.hip", "stage_models.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
+    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "plan.hpp", "stage_eval.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
     if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B", "../libmpcqp.so"], stdout=subprocess.DEVNULL)
     return SO_PATH

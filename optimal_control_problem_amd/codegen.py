@@ -1,0 +1,393 @@
+"""codegen: user-defined dynamics -> straight-line tape -> scalar-generic C++ functor -> gfx950 library.
+
+The reference turns the CasADi local-system function into C source, compiles it with gcc and dlopens the result when
+solver_settings.gen_code / load_lib are set (reference src/OptimalControlProblem.cpp:263-287,602-640).  CasADi is not
+available here; the equivalent for this engine is:
+
+1. trace(F, nx, nu): call the user's NumPy discrete map s_next = F(s, u) once on tracer objects; every arithmetic
+   operation / NumPy ufunc lands on a tape in SSA form (common subexpressions merged, constants folded);
+2. emit_functor(tape): the tape as a `template <class T> F(...)` functor in the form csrc/stage_models.hpp uses, so
+   the evaluation kernels (csrc/stage_kernels.hpp) instantiate it with double (merit) and with one-direction dual
+   numbers (Jacobian columns) exactly like the built-in zoo;
+3. build_device_library(...): hipcc --offload-arch=gfx950 -shared, loaded by mpcqp_stage_create_user;
+   build_host_library(...): the same functor compiled by g++ for CPU-side checks (tests, no GPU needed).
+
+Supported inside F: + - * / ** (integer powers), unary -, np.sin cos tan exp log sqrt tanh square negative, indexing
+s[..., i] / s[..., a:b], np.stack / np.concatenate along the last axis, Python and NumPy scalars as constants.
+Data-dependent branches cannot be traced (the same restriction CasADi SX has)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+
+_UNARY = {"neg": "-", "sin": "sm_sin", "cos": "sm_cos", "tan": "sm_tan", "exp": "sm_exp", "log": "sm_log", "sqrt": "sm_sqrt", "tanh": "sm_tanh"}
+_BINARY = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
+_NP_UNARY = {"neg": np.negative, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log, "sqrt": np.sqrt, "tanh": np.tanh}
+
+
+class Tape:
+    """SSA tape: nodes[i] = ("in", k) | ("const", value) | (unary, a) | (binary, a, b); outputs = node ids."""
+
+    def __init__(self, n_in):
+        self.n_in = n_in
+        self.nodes = [("in", k) for k in range(n_in)]
+        self._memo = {}
+        self.outputs = []
+
+    def const(self, v):
+        return self._add(("const", float(v)))
+
+    def _add(self, node):
+        key = node if node[0] != "const" else ("const", np.float64(node[1]).tobytes())
+        if key in self._memo:
+            return self._memo[key]
+        self.nodes.append(node)
+        self._memo[key] = len(self.nodes) - 1
+        return len(self.nodes) - 1
+
+    def is_const(self, i):
+        return self.nodes[i][0] == "const"
+
+    def unary(self, op, a):
+        if self.is_const(a):
+            return self.const(_NP_UNARY[op](self.nodes[a][1]))
+        return self._add((op, a))
+
+    def binary(self, op, a, b):
+        if self.is_const(a) and self.is_const(b):
+            x, y = self.nodes[a][1], self.nodes[b][1]
+            return self.const({"add": x + y, "sub": x - y, "mul": x * y, "div": x / y}[op])
+        return self._add((op, a, b))
+
+    # -- reference evaluation (NumPy, any dtype incl. complex): the checker for the generated code
+    def evaluate(self, inputs):
+        vals = [None] * len(self.nodes)
+        for i, nd in enumerate(self.nodes):
+            k = nd[0]
+            if k == "in":
+                vals[i] = inputs[nd[1]]
+            elif k == "const":
+                vals[i] = nd[1]
+            elif k in _UNARY:
+                vals[i] = _NP_UNARY[k](vals[nd[1]])
+            else:
+                a, b = vals[nd[1]], vals[nd[2]]
+                vals[i] = a + b if k == "add" else a - b if k == "sub" else a * b if k == "mul" else a / b
+        return [vals[o] for o in self.outputs]
+
+    def live_nodes(self):
+        """ids reachable from the outputs, in order"""
+        need = set(); stack = list(self.outputs)
+        while stack:
+            i = stack.pop()
+            if i in need:
+                continue
+            need.add(i)
+            nd = self.nodes[i]
+            if nd[0] in _UNARY:
+                stack.append(nd[1])
+            elif nd[0] in _BINARY:
+                stack += [nd[1], nd[2]]
+        return sorted(need)
+
+
+class TS:
+    """scalar tracer"""
+    __array_priority__ = 1000
+
+    def __init__(self, tape, idx):
+        self.tape, self.idx = tape, idx
+
+    @staticmethod
+    def _lift(tape, v):
+        if isinstance(v, TS):
+            return v
+        if isinstance(v, (int, float, np.integer, np.floating)):
+            return TS(tape, tape.const(v))
+        if isinstance(v, np.ndarray) and v.ndim == 0:
+            return TS(tape, tape.const(float(v)))
+        raise TypeError("cannot trace a value of type %s" % type(v).__name__)
+
+    def _bin(self, op, other, swap=False):
+        if isinstance(other, TV):
+            return other._bin(op, self, swap=not swap)
+        o = TS._lift(self.tape, other)
+        a, b = (o, self) if swap else (self, o)
+        return TS(self.tape, self.tape.binary(op, a.idx, b.idx))
+
+    def __add__(self, o): return self._bin("add", o)
+    def __radd__(self, o): return self._bin("add", o, True)
+    def __sub__(self, o): return self._bin("sub", o)
+    def __rsub__(self, o): return self._bin("sub", o, True)
+    def __mul__(self, o): return self._bin("mul", o)
+    def __rmul__(self, o): return self._bin("mul", o, True)
+    def __truediv__(self, o): return self._bin("div", o)
+    def __rtruediv__(self, o): return self._bin("div", o, True)
+    def __neg__(self): return TS(self.tape, self.tape.unary("neg", self.idx))
+    def __pos__(self): return self
+
+    def __pow__(self, e):
+        if isinstance(e, (int, np.integer)) or (isinstance(e, float) and e == int(e)):
+            e = int(e)
+            if e == 0:
+                return TS(self.tape, self.tape.const(1.0))
+            r = None; base = self; k = abs(e)
+            while k:
+                if k & 1:
+                    r = base if r is None else r * base
+                k >>= 1
+                if k:
+                    base = base * base
+            return r if e > 0 else 1.0 / r
+        if e == 0.5:
+            return TS(self.tape, self.tape.unary("sqrt", self.idx))
+        raise TypeError("only integer powers and ** 0.5 can be traced")
+
+    def __bool__(self):
+        raise TypeError("data-dependent branches cannot be traced (the dynamics must be straight-line code)")
+
+    def _cmp(self, o):
+        return self.__bool__()
+
+    __lt__ = __le__ = __gt__ = __ge__ = _cmp
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        return _ufunc(self.tape, ufunc, method, inputs, kw)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _array_function(self.tape, func, args, kwargs)
+
+
+class TV:
+    """vector tracer standing for an array [..., k] (leading axes are the batch the device kernel supplies)"""
+    __array_priority__ = 1000
+
+    def __init__(self, tape, items):
+        self.tape, self.items = tape, list(items)
+
+    @property
+    def shape(self):
+        return (len(self.items),)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            key = [k for k in key if k is not Ellipsis]
+            if len(key) != 1:
+                raise IndexError("index the last axis only: s[..., i] or s[..., a:b]")
+            key = key[0]
+        if isinstance(key, slice):
+            return TV(self.tape, self.items[key])
+        if isinstance(key, (int, np.integer)):
+            return self.items[int(key)]
+        if isinstance(key, (list, np.ndarray)):
+            return TV(self.tape, [self.items[int(i)] for i in key])
+        raise IndexError("unsupported index %r" % (key,))
+
+    def __iter__(self):
+        return iter(self.items)
+
+    def _bin(self, op, other, swap=False):
+        if isinstance(other, TV):
+            if len(other) != len(self):
+                raise ValueError("shape mismatch %d vs %d" % (len(self), len(other)))
+            others = other.items
+        elif isinstance(other, np.ndarray) and other.ndim >= 1:
+            if other.shape[-1] != len(self) or other.size != len(self):
+                raise ValueError("constant array must have the vector's length")
+            others = [float(v) for v in other.ravel()]
+        else:
+            others = [other] * len(self)
+        out = []
+        for a, b in zip(self.items, others):
+            out.append(a._bin(op, b, swap))
+        return TV(self.tape, out)
+
+    def __add__(self, o): return self._bin("add", o)
+    def __radd__(self, o): return self._bin("add", o, True)
+    def __sub__(self, o): return self._bin("sub", o)
+    def __rsub__(self, o): return self._bin("sub", o, True)
+    def __mul__(self, o): return self._bin("mul", o)
+    def __rmul__(self, o): return self._bin("mul", o, True)
+    def __truediv__(self, o): return self._bin("div", o)
+    def __rtruediv__(self, o): return self._bin("div", o, True)
+    def __neg__(self): return TV(self.tape, [-a for a in self.items])
+    def __pow__(self, e): return TV(self.tape, [a ** e for a in self.items])
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        return _ufunc(self.tape, ufunc, method, inputs, kw)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _array_function(self.tape, func, args, kwargs)
+
+
+_UFUNC_BIN = {np.add: "add", np.subtract: "sub", np.multiply: "mul", np.true_divide: "div"}
+_UFUNC_UN = {np.negative: "neg", np.sin: "sin", np.cos: "cos", np.tan: "tan", np.exp: "exp", np.log: "log", np.sqrt: "sqrt", np.tanh: "tanh"}
+
+
+def _ufunc(tape, ufunc, method, inputs, kw):
+    if method != "__call__" or kw.get("out") is not None:
+        return NotImplemented
+    if ufunc in _UFUNC_BIN:
+        a, b = inputs
+        op = _UFUNC_BIN[ufunc]
+        if isinstance(a, (TS, TV)):
+            return a._bin(op, b)
+        return b._bin(op, a, True)
+    if ufunc in _UFUNC_UN:
+        (a,) = inputs
+        op = _UFUNC_UN[ufunc]
+        if isinstance(a, TV):
+            return TV(tape, [TS(tape, tape.unary(op, x.idx)) for x in a.items])
+        return TS(tape, tape.unary(op, a.idx))
+    if ufunc is np.square:
+        (a,) = inputs
+        return a * a
+    if ufunc is np.power:
+        a, e = inputs
+        return a ** e
+    if ufunc is np.positive:
+        return inputs[0]
+    raise TypeError("NumPy function %s cannot be traced" % ufunc.__name__)
+
+
+def _array_function(tape, func, args, kwargs):
+    if func in (np.stack, np.concatenate):
+        seq = args[0]
+        axis = kwargs.get("axis", args[1] if len(args) > 1 else 0)
+        if axis not in (-1,) and not (axis == 0 and all(isinstance(v, (TS, TV, int, float)) for v in seq)):
+            raise TypeError("stack / concatenate along the last axis only")
+        items = []
+        for v in seq:
+            if isinstance(v, TV):
+                if func is np.stack:
+                    raise TypeError("np.stack of vectors is not traceable; use np.concatenate")
+                items += v.items
+            else:
+                items.append(TS._lift(tape, v))
+        return TV(tape, items)
+    raise TypeError("NumPy function %s cannot be traced" % func.__name__)
+
+
+def trace(F, nx, nu):
+    """Run F once on tracers.  F(s, u) -> s_next with s [..., nx], u [..., nu] (the contract of models.StageOCP.F)."""
+    tape = Tape(nx + nu)
+    s = TV(tape, [TS(tape, i) for i in range(nx)])
+    u = TV(tape, [TS(tape, nx + i) for i in range(nu)])
+    out = F(s, u)
+    if isinstance(out, TS):
+        out = TV(tape, [out])
+    if isinstance(out, (list, tuple)):
+        out = TV(tape, [TS._lift(tape, v) for v in out])
+    if not isinstance(out, TV) or len(out) != nx:
+        raise ValueError("F must return the next state, %d components" % nx)
+    tape.outputs = [TS._lift(tape, v).idx for v in out.items]
+    tape.nx, tape.nu = nx, nu
+    return tape
+
+
+# ------------------------------------------------------------------------------------------------- emission
+def _lit(v):
+    if v != v or v in (float("inf"), float("-inf")):
+        raise ValueError("non-finite constant in the traced dynamics")
+    return repr(float(v)) if "e" in repr(float(v)) or "." in repr(float(v)) else repr(float(v)) + ".0"
+
+
+def emit_functor(tape, name="SmUser"):
+    """C++ source of the functor (same shape as the zoo's functors in csrc/stage_models.hpp)"""
+    nx, nu = tape.nx, tape.nu
+    live = tape.live_nodes()
+    ref = {}
+    lines = []
+    for i in live:
+        nd = tape.nodes[i]
+        if nd[0] == "in":
+            ref[i] = "s[%d]" % nd[1] if nd[1] < nx else "u[%d]" % (nd[1] - nx)
+        elif nd[0] == "const":
+            ref[i] = _lit(nd[1])
+        elif nd[0] in _UNARY:
+            f = _UNARY[nd[0]]
+            expr = "-%s" % ref[nd[1]] if nd[0] == "neg" else "%s(%s)" % (f, ref[nd[1]])
+            lines.append("    const T w%d = %s;" % (i, expr)); ref[i] = "w%d" % i
+        else:
+            lines.append("    const T w%d = %s %s %s;" % (i, ref[nd[1]], _BINARY[nd[0]], ref[nd[2]])); ref[i] = "w%d" % i
+    for r, o in enumerate(tape.outputs):
+        nd = tape.nodes[o]
+        lines.append("    out[%d] = %s;" % (r, "T{} + %s" % ref[o] if nd[0] == "const" else ref[o]))
+    body = "\n".join(lines)
+    return ("struct %s {\n  static constexpr int nx = %d, nu = %d;\n"
+            "  template <class T> SM_HD static void F(const double *, double, const T *s, const T *u, T *out) {\n%s\n  }\n};\n" % (name, nx, nu, body))
+
+
+_DEVICE_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- do not edit
+#include "stage_kernels.hpp"
+
+%(functor)s
+extern "C" {
+int mpcqp_user_abi() { return STAGE_ABI_VERSION; }
+void mpcqp_user_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
+int mpcqp_user_eval(const StageDev *sd, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
+                    const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, void *stream) {
+  return (int)stage_launch_eval<SmUser>(*sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, (hipStream_t)stream);
+}
+int mpcqp_user_merit(const StageDev *sd, int batch, const double *p, const double *x, double *f, double *gmax, void *stream) {
+  return (int)stage_launch_merit<SmUser>(*sd, batch, p, x, f, gmax, (hipStream_t)stream);
+}
+}
+'''
+
+_HOST_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- host build of the same functor, for checks without a GPU
+#include "stage_models.hpp"
+
+%(functor)s
+extern "C" {
+void user_host_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
+// out [nx], jac [nx * (nx + nu)] row-major: forward-mode duals, one direction per pass (what a device thread does)
+void user_host_eval(const double *s, const double *u, double *out, double *jac) {
+  constexpr int nx = SmUser::nx, nu = SmUser::nu, f = nx + nu;
+  for (int c = 0; c < f; c++) {
+    Dual sd[nx], ud[nu], od[nx];
+    for (int i = 0; i < nx; i++) sd[i] = {s[i], i == c ? 1.0 : 0.0};
+    for (int i = 0; i < nu; i++) ud[i] = {u[i], nx + i == c ? 1.0 : 0.0};
+    SmUser::F<Dual>(nullptr, 0.0, sd, ud, od);
+    for (int r = 0; r < nx; r++) { jac[r * f + c] = od[r].d; out[r] = od[r].v; }
+  }
+}
+}
+'''
+
+
+def cache_dir():
+    d = os.environ.get("MPCQP_CACHE_DIR") or os.path.join(_HERE, "_gen")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _build(src_text, suffix, cmd_prefix):
+    key = hashlib.sha256((src_text + open(os.path.join(CSRC, "stage_kernels.hpp")).read() +
+                          open(os.path.join(CSRC, "stage_models.hpp")).read()).encode()).hexdigest()[:20]
+    base = os.path.join(cache_dir(), "user_%s_%s" % (suffix, key))
+    so, src = base + ".so", base + (".hip" if suffix == "dev" else ".cpp")
+    if not os.path.exists(so):
+        with open(src, "w") as fh:
+            fh.write(src_text)
+        tmp = so + ".tmp%d" % os.getpid()
+        subprocess.check_call(cmd_prefix + ["-I", CSRC, "-shared", "-fPIC", "-o", tmp, src])
+        os.replace(tmp, so)
+    return so
+
+
+def build_device_library(tape):
+    """gfx950 shared library for mpcqp_stage_create_user (hipcc cross-compiles without a GPU); cached by content"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return _build(_DEVICE_TMPL % {"functor": emit_functor(tape)}, "dev", [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950"])
+
+
+def build_host_library(tape):
+    return _build(_HOST_TMPL % {"functor": emit_functor(tape)}, "host", ["g++", "-O2", "-std=c++17", "-ffp-contract=off"])

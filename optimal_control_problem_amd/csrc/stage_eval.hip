@@ -9,20 +9,18 @@
 // columns, so every store stream is contiguous across a wave; the value part of F is recomputed by the f lanes of a
 // stage (cheaper than exchanging it).  HBM-bound: one pass, algorithmic bytes = inputs + outputs.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <string>
 #include <vector>
 
 #include "../../include/mpcqp.h"
 #include "common.hpp"
-#include "stage_models.hpp"
+#include "stage_kernels.hpp"
 
-struct StageDev {
-  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;
-  double dt;
-  double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
-  const int *Pp, *Ap;   // device copies of the column pointers
-};
+typedef int (*user_eval_fn)(const StageDev *, int, const double *, const double *, const double *, const double *, const double *,
+                            const double *, double *, double *, double *, double *, double *, void *);
+typedef int (*user_merit_fn)(const StageDev *, int, const double *, const double *, double *, double *, void *);
 
 struct mpcqp_stage {
   mpcqp_stage_desc desc;
@@ -30,95 +28,10 @@ struct mpcqp_stage {
   int device = 0;
   std::vector<int> Pp, Pi, Ap, Ai;
   int *dPp = nullptr, *dAp = nullptr;
+  void *user_lib = nullptr;           // dlopen handle of a generated dynamics library (model == MPCQP_MODEL_USER)
+  user_eval_fn user_eval = nullptr;
+  user_merit_fn user_merit = nullptr;
 };
-
-template <class M>
-__global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch, const double *__restrict__ p, const double *__restrict__ x,
-                                                         const double *__restrict__ lbx, const double *__restrict__ ubx,
-                                                         const double *__restrict__ lbg, const double *__restrict__ ubg,
-                                                         double *__restrict__ P, double *__restrict__ q, double *__restrict__ A,
-                                                         double *__restrict__ l, double *__restrict__ u) {
-  constexpr int nx = M::nx, nu = M::nu, f = nx + nu;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = sd.n, N = sd.N;
-  if (gid >= (long)batch * n) return;
-  const int b = (int)(gid / n), j = (int)(gid - (long)b * n);
-  const double *pb = p + (long)b * nx, *xb = x + (long)b * sd.nvar;
-  double *Pc = P + (long)b * sd.nnzP + sd.Pp[j], *Ac = A + (long)b * sd.nnzA + sd.Ap[j];
-  double *qb = q + (long)b * n, *lb = l + (long)b * sd.m, *ub = u + (long)b * sd.m;
-  if (j < nx) {
-    // column p_i: H = d2f/dp_i2 = 2 N Q_i, d2f/dp_i ds_k[i] = -2 Q_i; grad = -2 Q_i sum_k (s_k[i] - p_i); rows l = u = p - p
-    const double Qi = sd.Q[j], pi = pb[j];
-    double e = 0.0;
-    Pc[0] = 2.0 * N * Qi;
-    for (int k = 0; k < N; k++) { Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
-    qb[j] = -2.0 * e;
-    Ac[0] = 1.0;
-    lb[j] = pi - pi; ub[j] = pi - pi;
-    return;
-  }
-  const int jj = j - nx, k = jj / f, c = jj - k * f;
-  const double *fr = xb + k * f;
-  const double xv = fr[c];
-  if (c < nx) {
-    const double Qc = sd.Q[c];
-    Pc[0] = -2.0 * Qc; Pc[1] = 2.0 * Qc;
-    qb[j] = 2.0 * (xv - pb[c]) * Qc;
-  } else {
-    const double Rc = sd.R[c - nx];
-    Pc[0] = 2.0 * Rc;
-    qb[j] = 2.0 * xv * Rc;
-  }
-  lb[j] = lbx[(long)b * sd.nvar + jj] - xv; ub[j] = ubx[(long)b * sd.nvar + jj] - xv;
-  int a = 0;
-  Ac[a++] = 1.0;
-  if (k >= 1 && c < nx) Ac[a++] = 1.0;
-  if (k < N - 1) {
-    Dual s[nx], uu[nu], out[nx];
-#pragma unroll
-    for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
-#pragma unroll
-    for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
-    M::template F<Dual>(sd.par, sd.dt, s, uu, out);
-#pragma unroll
-    for (int r = 0; r < nx; r++) Ac[a + r] = -out[r].d;
-    if (c < nx) {
-      double Fc = 0.0;
-#pragma unroll
-      for (int r = 0; r < nx; r++) Fc = r == c ? out[r].v : Fc;
-      const double g = fr[f + c] - Fc;
-      const int row = n + k * nx + c; const long gi = (long)b * sd.ng + k * nx + c;
-      lb[row] = lbg[gi] - g; ub[row] = ubg[gi] - g;
-    }
-  }
-}
-
-// one wave per instance: lanes stride over the frames, butterfly reduction (fixed order => deterministic)
-template <class M>
-__global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch, const double *__restrict__ p, const double *__restrict__ x,
-                                                          double *__restrict__ fout, double *__restrict__ gout) {
-  constexpr int nx = M::nx, nu = M::nu, f = nx + nu;
-  const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= batch) return;
-  const double *pb = p + (long)b * nx, *xb = x + (long)b * sd.nvar;
-  double cost = 0.0, gmax = 0.0;
-  for (int k = lane; k < sd.N; k += 64) {
-    const double *fr = xb + k * f;
-    double s[nx], uu[nu];
-#pragma unroll
-    for (int i = 0; i < nx; i++) { s[i] = fr[i]; const double e = s[i] - pb[i]; cost += e * e * sd.Q[i]; }
-#pragma unroll
-    for (int i = 0; i < nu; i++) { uu[i] = fr[nx + i]; cost += uu[i] * uu[i] * sd.R[i]; }
-    if (k < sd.N - 1) {
-      double out[nx];
-      M::template F<double>(sd.par, sd.dt, s, uu, out);
-#pragma unroll
-      for (int i = 0; i < nx; i++) gmax = fmax(gmax, fabs(fr[f + i] - out[i]));
-    }
-  }
-  for (int o = 32; o >= 1; o >>= 1) { cost += __shfl_xor(cost, o, 64); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
-  if (lane == 0) { if (fout) fout[b] = cost; if (gout) gout[b] = gmax; }
-}
 
 __global__ void __launch_bounds__(256) stage_step_kernel(int batch, int nvar, int n, int np, double alpha, const double *__restrict__ dw,
                                                          double *__restrict__ x, double *__restrict__ step_max, const int *__restrict__ status) {
@@ -170,19 +83,12 @@ int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d) {
   return MPCQP_OK;
 }
 
-int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out) {
-  if (!out) return mpcqp_set_error(MPCQP_ERR_ARG, "out is null");
-  *out = nullptr;
-  if (!d) return mpcqp_set_error(MPCQP_ERR_ARG, "desc is null");
-  if (d->model < 0 || d->model >= SM_NMODELS) return mpcqp_set_error(MPCQP_ERR_ARG, "unknown model");
-  if (d->horizon < 2 || !(d->dt > 0.0)) return mpcqp_set_error(MPCQP_ERR_ARG, "horizon must be >= 2 and dt > 0");
+static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, mpcqp_stage *s) {
   int dev = 0;
   if (int rc = mpcqp_pick_device(d->device, &dev)) return rc;
-  mpcqp_stage *s = new mpcqp_stage();
   s->desc = *d; s->device = dev;
   StageDev &sd = s->sd;
-  sd.model = d->model; sd.N = d->horizon; sd.dt = d->dt;
-  sm_model_dims(d->model, &sd.nx, &sd.nu);
+  sd.model = d->model; sd.N = d->horizon; sd.dt = d->dt; sd.nx = nx; sd.nu = nu;
   sd.f = sd.nx + sd.nu; sd.np = sd.nx; sd.nvar = sd.N * sd.f; sd.n = sd.np + sd.nvar;
   sd.ng = (sd.N - 1) * sd.nx; sd.m = sd.n + sd.ng;
   for (int i = 0; i < SM_MAXNX; i++) sd.Q[i] = d->Q[i];
@@ -190,15 +96,51 @@ int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out) {
   for (int i = 0; i < SM_NPAR; i++) sd.par[i] = d->par[i];
   sm_build_pattern(sd.nx, sd.nu, sd.N, s->Pp, s->Pi, s->Ap, s->Ai);
   sd.nnzP = (int)s->Pi.size(); sd.nnzA = (int)s->Ai.size();
-  auto bail = [&](int rc) { mpcqp_stage_destroy(s); return rc; };
-  if (hipSetDevice(dev) != hipSuccess) return bail(mpcqp_set_error(MPCQP_ERR_HIP, "hipSetDevice failed"));
+  if (hipSetDevice(dev) != hipSuccess) return mpcqp_set_error(MPCQP_ERR_HIP, "hipSetDevice failed");
   const size_t bytes = (size_t)(sd.n + 1) * sizeof(int);
   if (hipMalloc(&s->dPp, bytes) != hipSuccess || hipMalloc(&s->dAp, bytes) != hipSuccess)
-    return bail(mpcqp_set_error(MPCQP_ERR_HIP, "hipMalloc of the column pointers failed"));
+    return mpcqp_set_error(MPCQP_ERR_HIP, "hipMalloc of the column pointers failed");
   if (hipMemcpy(s->dPp, s->Pp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->dAp, s->Ap.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
-    return bail(mpcqp_set_error(MPCQP_ERR_HIP, "upload of the column pointers failed"));
+    return mpcqp_set_error(MPCQP_ERR_HIP, "upload of the column pointers failed");
   sd.Pp = s->dPp; sd.Ap = s->dAp;
+  return MPCQP_OK;
+}
+
+int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out) {
+  if (!out) return mpcqp_set_error(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!d) return mpcqp_set_error(MPCQP_ERR_ARG, "desc is null");
+  if (d->model < 0 || d->model >= SM_NMODELS) return mpcqp_set_error(MPCQP_ERR_ARG, "unknown model");
+  if (d->horizon < 2 || !(d->dt > 0.0)) return mpcqp_set_error(MPCQP_ERR_ARG, "horizon must be >= 2 and dt > 0");
+  int nx, nu;
+  sm_model_dims(d->model, &nx, &nu);
+  mpcqp_stage *s = new mpcqp_stage();
+  if (int rc = stage_create_common(d, nx, nu, s)) { mpcqp_stage_destroy(s); return rc; }
+  *out = s;
+  return MPCQP_OK;
+}
+
+int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path, mpcqp_stage **out) {
+  if (!out) return mpcqp_set_error(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!d || !library_path) return mpcqp_set_error(MPCQP_ERR_ARG, "null argument");
+  if (d->horizon < 2 || !(d->dt > 0.0)) return mpcqp_set_error(MPCQP_ERR_ARG, "horizon must be >= 2 and dt > 0");
+  void *lib = dlopen(library_path, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return mpcqp_set_error(MPCQP_ERR_ARG, std::string("cannot load the dynamics library: ") + dlerror());
+  auto abi = (int (*)())dlsym(lib, "mpcqp_user_abi");
+  auto dims = (void (*)(int *, int *))dlsym(lib, "mpcqp_user_dims");
+  auto ev = (user_eval_fn)dlsym(lib, "mpcqp_user_eval");
+  auto me = (user_merit_fn)dlsym(lib, "mpcqp_user_merit");
+  if (!abi || !dims || !ev || !me) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_ARG, "the library does not export mpcqp_user_abi/dims/eval/merit"); }
+  if (abi() != STAGE_ABI_VERSION) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_ARG, "the library was generated for another version of the stage kernels; regenerate it"); }
+  int nx = 0, nu = 0;
+  dims(&nx, &nu);
+  if (nx <= 0 || nx > SM_MAXNX || nu <= 0 || nu > SM_MAXNU) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_LIMIT, "nx must be in 1..16 and nu in 1..8"); }
+  mpcqp_stage *s = new mpcqp_stage();
+  s->user_lib = lib; s->user_eval = ev; s->user_merit = me;
+  mpcqp_stage_desc dd = *d; dd.model = MPCQP_MODEL_USER;
+  if (int rc = stage_create_common(&dd, nx, nu, s)) { mpcqp_stage_destroy(s); return rc; }
   *out = s;
   return MPCQP_OK;
 }
@@ -208,6 +150,7 @@ void mpcqp_stage_destroy(mpcqp_stage *s) {
   (void)hipSetDevice(s->device);
   if (s->dPp) (void)hipFree(s->dPp);
   if (s->dAp) (void)hipFree(s->dAp);
+  if (s->user_lib) dlclose(s->user_lib);
   delete s;
 }
 
@@ -225,13 +168,6 @@ int mpcqp_stage_pattern(const mpcqp_stage *s, int *Pp, int *Pi, int *Ap, int *Ai
   return MPCQP_OK;
 }
 
-#define STAGE_DISPATCH(KERNEL, GRID, ...)                                                                               \
-  switch (s->sd.model) {                                                                                                \
-    case SM_DOUBLE_INTEGRATOR: KERNEL<SmDoubleIntegrator><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                    \
-    case SM_QUADROTOR: KERNEL<SmQuadrotor><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                   \
-    case SM_CARTPOLE: KERNEL<SmCartPole><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                     \
-  }
-
 int mpcqp_stage_eval(mpcqp_stage *s, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
                      const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, void *stream) {
   if (!s) return mpcqp_set_error(MPCQP_ERR_ARG, "stage handle is null");
@@ -239,10 +175,14 @@ int mpcqp_stage_eval(mpcqp_stage *s, int batch, const double *p, const double *x
   if (!p || !x || !lbx || !ubx || !lbg || !ubg || !P || !q || !A || !l || !u) return mpcqp_set_error(MPCQP_ERR_ARG, "null data pointer");
   MPCQP_HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  const long threads = (long)batch * s->sd.n;
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  STAGE_DISPATCH(stage_eval_kernel, grid, s->sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u)
-  MPCQP_HIPCHK(hipGetLastError());
+  hipError_t e = hipSuccess;
+  switch (s->sd.model) {
+    case SM_DOUBLE_INTEGRATOR: e = stage_launch_eval<SmDoubleIntegrator>(s->sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, st); break;
+    case SM_QUADROTOR: e = stage_launch_eval<SmQuadrotor>(s->sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, st); break;
+    case SM_CARTPOLE: e = stage_launch_eval<SmCartPole>(s->sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, st); break;
+    case MPCQP_MODEL_USER: e = (hipError_t)s->user_eval(&s->sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, stream); break;
+  }
+  MPCQP_HIPCHK(e);
   return MPCQP_OK;
 }
 
@@ -251,9 +191,14 @@ int mpcqp_stage_merit(mpcqp_stage *s, int batch, const double *p, const double *
   if (batch <= 0 || !p || !x) return mpcqp_set_error(MPCQP_ERR_ARG, "bad batch or null data pointer");
   MPCQP_HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((batch + 3) / 4);
-  STAGE_DISPATCH(stage_merit_kernel, grid, s->sd, batch, p, x, f, gmax)
-  MPCQP_HIPCHK(hipGetLastError());
+  hipError_t e = hipSuccess;
+  switch (s->sd.model) {
+    case SM_DOUBLE_INTEGRATOR: e = stage_launch_merit<SmDoubleIntegrator>(s->sd, batch, p, x, f, gmax, st); break;
+    case SM_QUADROTOR: e = stage_launch_merit<SmQuadrotor>(s->sd, batch, p, x, f, gmax, st); break;
+    case SM_CARTPOLE: e = stage_launch_merit<SmCartPole>(s->sd, batch, p, x, f, gmax, st); break;
+    case MPCQP_MODEL_USER: e = (hipError_t)s->user_merit(&s->sd, batch, p, x, f, gmax, stream); break;
+  }
+  MPCQP_HIPCHK(e);
   return MPCQP_OK;
 }
 

@@ -1,0 +1,120 @@
+// stage_kernels.hpp -- device templates of the local-system evaluation (see stage_eval.hip for the design notes).
+// Included by stage_eval.hip (the built-in zoo) and by the translation units optimal_control_problem_amd/codegen.py
+// generates for user-defined dynamics (the native analogue of the reference's gen_code / load_lib flow,
+// reference src/OptimalControlProblem.cpp:263-287,602-640).  STAGE_ABI_VERSION guards the StageDev layout shared between
+// libmpcqp.so and a generated library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "stage_models.hpp"
+
+#define STAGE_ABI_VERSION 1
+
+struct StageDev {
+  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;
+  double dt;
+  double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
+  const int *Pp, *Ap;   // device copies of the column pointers
+};
+
+template <class M>
+__global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch, const double *__restrict__ p, const double *__restrict__ x,
+                                                         const double *__restrict__ lbx, const double *__restrict__ ubx,
+                                                         const double *__restrict__ lbg, const double *__restrict__ ubg,
+                                                         double *__restrict__ P, double *__restrict__ q, double *__restrict__ A,
+                                                         double *__restrict__ l, double *__restrict__ u) {
+  constexpr int nx = M::nx, nu = M::nu, f = nx + nu;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = sd.n, N = sd.N;
+  if (gid >= (long)batch * n) return;
+  const int b = (int)(gid / n), j = (int)(gid - (long)b * n);
+  const double *pb = p + (long)b * nx, *xb = x + (long)b * sd.nvar;
+  double *Pc = P + (long)b * sd.nnzP + sd.Pp[j], *Ac = A + (long)b * sd.nnzA + sd.Ap[j];
+  double *qb = q + (long)b * n, *lb = l + (long)b * sd.m, *ub = u + (long)b * sd.m;
+  if (j < nx) {
+    // column p_i: H = d2f/dp_i2 = 2 N Q_i, d2f/dp_i ds_k[i] = -2 Q_i; grad = -2 Q_i sum_k (s_k[i] - p_i); rows l = u = p - p
+    const double Qi = sd.Q[j], pi = pb[j];
+    double e = 0.0;
+    Pc[0] = 2.0 * N * Qi;
+    for (int k = 0; k < N; k++) { Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
+    qb[j] = -2.0 * e;
+    Ac[0] = 1.0;
+    lb[j] = pi - pi; ub[j] = pi - pi;
+    return;
+  }
+  const int jj = j - nx, k = jj / f, c = jj - k * f;
+  const double *fr = xb + k * f;
+  const double xv = fr[c];
+  if (c < nx) {
+    const double Qc = sd.Q[c];
+    Pc[0] = -2.0 * Qc; Pc[1] = 2.0 * Qc;
+    qb[j] = 2.0 * (xv - pb[c]) * Qc;
+  } else {
+    const double Rc = sd.R[c - nx];
+    Pc[0] = 2.0 * Rc;
+    qb[j] = 2.0 * xv * Rc;
+  }
+  lb[j] = lbx[(long)b * sd.nvar + jj] - xv; ub[j] = ubx[(long)b * sd.nvar + jj] - xv;
+  int a = 0;
+  Ac[a++] = 1.0;
+  if (k >= 1 && c < nx) Ac[a++] = 1.0;
+  if (k < N - 1) {
+    Dual s[nx], uu[nu], out[nx];
+#pragma unroll
+    for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
+#pragma unroll
+    for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
+    M::template F<Dual>(sd.par, sd.dt, s, uu, out);
+#pragma unroll
+    for (int r = 0; r < nx; r++) Ac[a + r] = -out[r].d;
+    if (c < nx) {
+      double Fc = 0.0;
+#pragma unroll
+      for (int r = 0; r < nx; r++) Fc = r == c ? out[r].v : Fc;
+      const double g = fr[f + c] - Fc;
+      const int row = n + k * nx + c; const long gi = (long)b * sd.ng + k * nx + c;
+      lb[row] = lbg[gi] - g; ub[row] = ubg[gi] - g;
+    }
+  }
+}
+
+// one wave per instance: lanes stride over the frames, butterfly reduction (fixed order => deterministic)
+template <class M>
+__global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch, const double *__restrict__ p, const double *__restrict__ x,
+                                                          double *__restrict__ fout, double *__restrict__ gout) {
+  constexpr int nx = M::nx, nu = M::nu, f = nx + nu;
+  const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const double *pb = p + (long)b * nx, *xb = x + (long)b * sd.nvar;
+  double cost = 0.0, gmax = 0.0;
+  for (int k = lane; k < sd.N; k += 64) {
+    const double *fr = xb + k * f;
+    double s[nx], uu[nu];
+#pragma unroll
+    for (int i = 0; i < nx; i++) { s[i] = fr[i]; const double e = s[i] - pb[i]; cost += e * e * sd.Q[i]; }
+#pragma unroll
+    for (int i = 0; i < nu; i++) { uu[i] = fr[nx + i]; cost += uu[i] * uu[i] * sd.R[i]; }
+    if (k < sd.N - 1) {
+      double out[nx];
+      M::template F<double>(sd.par, sd.dt, s, uu, out);
+#pragma unroll
+      for (int i = 0; i < nx; i++) gmax = fmax(gmax, fabs(fr[f + i] - out[i]));
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) { cost += __shfl_xor(cost, o, 64); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }
+  if (lane == 0) { if (fout) fout[b] = cost; if (gout) gout[b] = gmax; }
+}
+
+
+// launchers shared by the zoo dispatch and generated libraries
+template <class M>
+inline hipError_t stage_launch_eval(const StageDev &sd, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
+                                    const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, hipStream_t st) {
+  const long threads = (long)batch * sd.n;
+  stage_eval_kernel<M><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u);
+  return hipGetLastError();
+}
+template <class M>
+inline hipError_t stage_launch_merit(const StageDev &sd, int batch, const double *p, const double *x, double *f, double *gmax, hipStream_t st) {
+  stage_merit_kernel<M><<<(unsigned)((batch + 3) / 4), 256, 0, st>>>(sd, batch, p, x, f, gmax);
+  return hipGetLastError();
+}

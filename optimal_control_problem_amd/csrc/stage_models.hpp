@@ -32,6 +32,17 @@ SM_HD Dual operator/(Dual a, double b) { return {a.v / b, a.d / b}; }
 SM_HD Dual operator/(double a, Dual b) { const double q = a / b.v; return {q, -q * b.d / b.v}; }
 SM_HD Dual sm_sin(Dual a) { return {sin(a.v), cos(a.v) * a.d}; }
 SM_HD Dual sm_cos(Dual a) { return {cos(a.v), -sin(a.v) * a.d}; }
+SM_HD Dual sm_tan(Dual a) { const double t = tan(a.v); return {t, (1.0 + t * t) * a.d}; }
+SM_HD Dual sm_exp(Dual a) { const double e = exp(a.v); return {e, e * a.d}; }
+SM_HD Dual sm_log(Dual a) { return {log(a.v), a.d / a.v}; }
+SM_HD Dual sm_sqrt(Dual a) { const double r = sqrt(a.v); return {r, 0.5 * a.d / r}; }
+SM_HD Dual sm_tanh(Dual a) { const double t = tanh(a.v); return {t, (1.0 - t * t) * a.d}; }
+SM_HD Dual operator-(Dual a) { return {-a.v, -a.d}; }
+SM_HD double sm_tan(double a) { return tan(a); }
+SM_HD double sm_exp(double a) { return exp(a); }
+SM_HD double sm_log(double a) { return log(a); }
+SM_HD double sm_sqrt(double a) { return sqrt(a); }
+SM_HD double sm_tanh(double a) { return tanh(a); }
 SM_HD double sm_sin(double a) { return sin(a); }
 SM_HD double sm_cos(double a) { return cos(a); }
 SM_HD double sm_val(double a) { return a; }

@@ -14,7 +14,7 @@ batched local-system evaluator (models.StageOCP) that plays the role of the CasA
 import numpy as np
 
 from . import models
-from .sqp import SQPOptimizationSolver
+from .sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
 
 
 # ---------------------------------------------------------------------------------------------------- expressions
@@ -156,7 +156,10 @@ class OptimalControlProblem:
 
     SOLVER_TYPES = ("IPOPT", "SQP", "CUDA_SQP", "MIXED")
 
-    def __init__(self, configNode, batch=1, qp_solver=None):
+    def __init__(self, configNode, batch=1, qp_solver=None, device_resident=None):
+        """device_resident: run the whole SQP tick on the GPU -- the dynamics are traced, emitted as code and compiled for
+        gfx950 at genSolver() (codegen.py).  Default: the YAML's solver_settings.gen_code, the flag with which the reference
+        generates and compiles its C code at the same point (reference src/OptimalControlProblem.cpp:263-287)."""
         if not self.validateConfig(configNode):
             raise RuntimeError("Invalid configuration file")                        # OptimalControlProblem.cpp:16-18
         self.OCPConfigPtr_ = OCPConfig(configNode)
@@ -170,6 +173,7 @@ class OptimalControlProblem:
         self.solverType = method
         self.batch = int(batch)
         self._qp_solver = qp_solver
+        self.deviceResident = self.solverSettings["genCode"] if device_resident is None else bool(device_resident)
         self.constraints_, self.constraintNames_ = [], []
         self.constraintLowerBounds_, self.constraintUpperBounds_ = [], []
         self.costs_ = []
@@ -245,7 +249,10 @@ class OptimalControlProblem:
         self.model_ = self._compile_stage_model()
         options = {"max_iter": self.solverSettings["stepNum"], "alpha": self.solverSettings["alpha"],
                    "verbose": self.solverSettings["verbose"]}
-        self.OSQPSolverPtr_ = SQPOptimizationSolver(self.model_, options, batch=self.batch, qp_solver=self._qp_solver)
+        if self.deviceResident and self._qp_solver is None:
+            self.OSQPSolverPtr_ = DeviceSQPOptimizationSolver(self.model_, options, batch=self.batch)
+        else:
+            self.OSQPSolverPtr_ = SQPOptimizationSolver(self.model_, options, batch=self.batch, qp_solver=self._qp_solver)
 
     def _compile_stage_model(self):
         cfg = self.OCPConfigPtr_

@@ -104,7 +104,7 @@ class DeviceSQPOptimizationSolver:
     update (mpcqp_stage_step, :171-177) and objective (mpcqp_stage_merit, :180-181).  The iterate, bounds and QP data never
     visit the host; only the returned x / f do.  For the stage-OCP zoo models (models.StageOCP subclasses)."""
 
-    def __init__(self, nlp, options, batch=1, device=-1):
+    def __init__(self, nlp, options, batch=1, device=-1, codegen=None):
         import torch
         from .batch_qp import BatchQP
         from .stage_eval import StageEvaluator
@@ -117,7 +117,7 @@ class DeviceSQPOptimizationSolver:
         # extension: an instance whose QP is infeasible keeps its iterate (the reference adds the NaN solution, :171-177)
         self.skip_failed_steps = bool(options.get("skip_failed_steps", False))
         self.batch = int(batch)
-        self.ev = StageEvaluator(nlp, device=device)
+        self.ev = StageEvaluator(nlp, device=device, codegen=codegen)
         # reference SQPOptimizationSolver.cpp:80-85
         self.qp = BatchQP(self.ev.n, self.ev.m, self.batch, self.ev.Pp, self.ev.Pi, self.ev.Ap, self.ev.Ai,
                           eps_abs=1e-3, eps_rel=1e-3, max_iter=10000, warm_start=1 if self.warm_start_admm else 0, device=device)

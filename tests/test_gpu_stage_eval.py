@@ -124,3 +124,60 @@ def test_stage_errors(built):
     assert L.mpcqp_stage_eval(ev._h, 0, *([good[0].data_ptr()] * 11), None) == _lib.ERR_ARG
     assert L.mpcqp_stage_eval(ev._h, B, None, *([good[0].data_ptr()] * 10), None) == _lib.ERR_ARG
     ev.close()
+
+
+# ------------------------------------------------------------------------------------- generated (user) dynamics
+@pytest.mark.parametrize("name,N,B", [("quadrotor", 10, 40), ("cartpole", 30, 33)])
+def test_generated_dynamics_equal_builtin(built, name, N, B):
+    """the traced + generated + hipcc-compiled functor of a zoo model against the library's hand-written one"""
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    mdl, ls, meta = models.make_workload(name, B, N=N)
+    a = StageEvaluator(mdl); g = StageEvaluator(mdl, codegen=True)
+    assert g.library is not None and a.library is None and (g.Ai == a.Ai).all()
+    args = [_dev(meta[k]) for k in ("p", "x_iterate", "lbx", "ubx", "lbg", "ubg")]
+    oa = a.eval(*args); og = g.eval(*args)
+    for k in ("P", "q", "A", "l", "u"):
+        assert _close(og[k].cpu().numpy(), oa[k].cpu().numpy(), 1e-12), k
+    fa, ga = a.merit(args[0], args[1]); fg, gg = g.merit(args[0], args[1])
+    assert _close(fg.cpu().numpy(), fa.cpu().numpy(), 1e-12) and _close(gg.cpu().numpy(), ga.cpu().numpy(), 1e-10)
+    a.close(); g.close()
+
+
+def test_facade_with_custom_dynamics_runs_device_resident(built):
+    """OptimalControlProblem subclass with its own dynamics (not in the zoo): gen_code: true compiles them for the GPU and
+    the whole SQP tick stays on the device; same trajectory as the host path (NumPy local system + GPU QP)"""
+    import yaml
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem
+    from tests.test_codegen import pendulum_on_cart_with_drag
+    text = """
+      discretization_settings: {dt: 0.01, horizon: 12}
+      solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 0.7, step_num: 5}}
+      OCP_variables:
+        - {name: state, size: 3, lower_bound: [-.inf, -.inf, -3.0], upper_bound: [.inf, .inf, 3.0]}
+        - {name: input, size: 1, lower_bound: [-5.0], upper_bound: [5.0]}
+    """
+
+    class Pendulum(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_
+            ref = self.setReference(3)
+            for k in range(cfg.getHorizon()):
+                self.addVectorCost([5.0, 0.5, 0.2], cfg.getVariable(k, "state") - ref)
+                self.addVectorCost([0.05], cfg.getVariable(k, "input"))
+            for k in range(cfg.getHorizon() - 1):
+                self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"),
+                                           Dynamics(pendulum_on_cart_with_drag, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+
+    B = 12
+    rng = np.random.default_rng(8)
+    frame = np.concatenate([rng.normal(0, 0.4, (B, 3)), np.zeros((B, 1))], axis=1); ref = np.zeros((B, 3))
+    res = {}
+    for flag in ("false", "true"):
+        ocp = Pendulum(yaml.safe_load(text % flag), batch=B)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert ocp.deviceResident == (flag == "true")
+        res[flag] = ocp.computeOptimalTrajectory(frame, ref)
+        assert type(ocp.OSQPSolverPtr_).__name__ == ("DeviceSQPOptimizationSolver" if flag == "true" else "SQPOptimizationSolver")
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
+    assert np.abs(res["true"][:, :4] - frame).max() < 5e-3

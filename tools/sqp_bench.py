@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device-resident SQP tick (BASELINE config 4 shape): per SQP iteration
 mpcqp_stage_eval -> mpcqp_update(device) -> mpcqp_solve -> mpcqp_stage_step/merit, nothing crosses PCIe.
-usage: python tools/sqp_bench.py [workload] [horizon] [batch] [sqp_iters] [alpha] [warm 0|1] [host_batch] [carry_rho 0|1]
+usage: python tools/sqp_bench.py [workload] [horizon] [batch] [sqp_iters] [alpha] [warm 0|1] [host_batch] [carry_rho 0|1] [codegen 0|1]
 Prints one JSON line: kernel times from CUDA events on the launch stream, the host loop (NumPy local system + H2D) for
 comparison on `host_batch` instances."""
 import json
@@ -27,9 +27,10 @@ HB = int(sys.argv[7]) if len(sys.argv) > 7 else 1024
 mdl, ls, meta = models.make_workload(name, B, N=N)
 arg = {k: torch.as_tensor(meta[k], dtype=torch.float64, device="cuda") for k in ("lbx", "ubx", "lbg", "ubg", "p")}
 carry = bool(int(sys.argv[8])) if len(sys.argv) > 8 else False
+cg = bool(int(sys.argv[9])) if len(sys.argv) > 9 else False
 opt = {"max_iter": iters, "alpha": alpha, "warm_start_admm": warm, "carry_rho": carry}
 
-dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B)
+dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B, codegen=cg)
 dev.setInitialGuess(meta["x_iterate"])                      # start from the seeded iterate, not the reference's x = 0
 dev.getOptimalSolution(arg, to_host=False)                  # warm-up (first launches, allocator)
 dev.setInitialGuess(meta["x_iterate"]); dev.admm_iterations = []
@@ -64,7 +65,7 @@ host.setInitialGuess(hmeta["x_iterate"])
 t0 = time.perf_counter(); rh = host.getOptimalSolution(harg); t_host = time.perf_counter() - t0
 out = {
     "workload": "%s N=%d batch=%d, %d SQP iterations alpha=%g, ADMM warm start %s, rho carried %s" % (name, N, B, iters, alpha, warm, carry),
-    "device_loop_s": t_dev, "sqp_ticks_per_s": B / t_dev, "qp_solves_per_s": B * iters / t_dev,
+    "dynamics": "generated (codegen.py)" if cg else "built-in functor", "device_loop_s": t_dev, "sqp_ticks_per_s": B / t_dev, "qp_solves_per_s": B * iters / t_dev,
     "mean_admm_iters_per_sqp_iter": [round(float(v), 1) for v in admm],
     "eval_kernel_ms": eval_ms, "eval_GBps": bytes_eval / eval_ms / 1e6, "merit_step_ms": aux_ms,
     "final_objective_mean": float(res["f"].mean()), "final_dynamics_violation_max": float(dev.gmax.max()),
