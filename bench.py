@@ -176,6 +176,24 @@ def main():
                                                "LDL' %d waves/QP, factor blocks streamed from HBM" % (pinfo["variant"] - 100) if pinfo["variant"] >= 100 else
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
+        if world == 1 and not args.force_iters:
+            # the same step with the boundary handing over HOST buffers (what a CuCaQP-style caller does: pageable inputs in,
+            # x / status / iters out): H2D + kernel + D2H per step.  Reported beside `value`, never as `value`.
+            hx = np.empty((batch, ls.n)); hst = np.empty(batch, np.int32); hit = np.empty(batch, np.int32)
+            L = __import__("optimal_control_problem_amd._lib", fromlist=["lib"])
+            def host_step():
+                qp.update(ls.P, ls.q, ls.A, ls.l, ls.u)
+                qp.solve(stream)
+                L.check(L.lib().mpcqp_get(qp._h, hx.ctypes.data, None, None, hst.ctypes.data, hit.ctypes.data, None, L.MEM_HOST))
+            host_step()
+            th = time.perf_counter()
+            for _ in range(3):
+                host_step()
+            th = (time.perf_counter() - th) / 3
+            in_bytes = 8 * (ls.P.size + ls.q.size + ls.A.size + ls.l.size + ls.u.size); out_bytes = hx.nbytes + hst.nbytes + hit.nbytes
+            out["pcie_inclusive"] = {"value": batch / th, "unit": "QP solves/s", "ms_per_step": th * 1e3,
+                                     "host_bytes_in": int(in_bytes), "host_bytes_out": int(out_bytes),
+                                     "note": "pageable NumPy inputs copied by mpcqp_update(MPCQP_MEM_HOST), x/status/iters copied back"}
         if world == 1 and not args.no_cpu_baseline and not args.force_iters:
             # the oracle (CPU port of the same algorithm) on this box's host cores, bounded sample of the same workload
             from oracle import oracle as orc
