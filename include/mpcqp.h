@@ -90,6 +90,19 @@ int mpcqp_update(mpcqp_handle *h,
  * x0 [batch*n], y0 [batch*m]; honoured by the next solve when settings.warm_start != 0. */
 int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int mem);
 
+/* Kept workspace -- the fast path the reference's private, never-called CuCaQP::updateGradient / updateLowerBound /
+ * updateUpperBound were written for (CuCaQP.cpp:117-161), with the semantics of OSQP's osqp_update_data_vec: P and A, their
+ * scaling (D, E, c), the KKT factorisation and every instance's current (possibly adapted) rho stay from the previous solve on
+ * this handle; only q, l, u are replaced.  The next mpcqp_solve skips equilibration and factorisation; an instance is
+ * re-factorised only if one of its rows moved between loose / inequality / equality (its rho_i changes then), and an instance
+ * whose matrices were found non-convex stays MPCQP_NON_CVX.  x / y start from zero, or from mpcqp_warm_start when
+ * settings.warm_start is set.  Call order: mpcqp_keep_workspace(h, 1) -> mpcqp_update -> mpcqp_solve ->
+ * { mpcqp_update_vectors -> mpcqp_solve }*; mpcqp_update returns to a full setup.  Strides and mem as in mpcqp_update.
+ * MPCQP_ERR_STATE when there is no kept solve yet; MPCQP_ERR_LIMIT on the streaming kernel variant. */
+int mpcqp_keep_workspace(mpcqp_handle *h, int enable);
+int mpcqp_update_vectors(mpcqp_handle *h, const double *q, long strideq, const double *l, long stridel,
+                         const double *u, long strideu, int mem);
+
 /* Per-instance starting rho for the following solves (rho0 [batch]; entries <= 0 mean settings.rho; NULL returns to
  * settings.rho for all).  A kept OSQP workspace carries its adapted rho from one problem to the next
  * (osqp_update_* do not reset it) -- the behaviour the reference's unused update* members would have had

@@ -86,6 +86,24 @@ class BatchQP:
             args += [ptr, stride]
         _lib.check(_lib.lib().mpcqp_update(self._h, *args, mems.pop()))
 
+    def keep_workspace(self, enable=True):
+        """keep scaling, factorisation and rho across solves so that update_vectors() can skip the setup"""
+        _lib.check(_lib.lib().mpcqp_keep_workspace(self._h, 1 if enable else 0))
+
+    def update_vectors(self, q, l, u):
+        """replace q, l, u only (OSQP's osqp_update_data_vec on a kept workspace); needs keep_workspace() and a previous
+        update() + solve()"""
+        B = self.batch
+        items = [_ptr_stride(q, self.n, B, "q"), _ptr_stride(l, self.m, B, "l"), _ptr_stride(u, self.m, B, "u")]
+        mems = {it[2] for it in items if it[2] is not None}
+        if len(mems) != 1:
+            raise ValueError("q, l, u must live in the same memory space")
+        self._keep_vec = [it[3] for it in items]
+        args = []
+        for ptr, stride, _, _ in items:
+            args += [ptr, stride]
+        _lib.check(_lib.lib().mpcqp_update_vectors(self._h, *args, mems.pop()))
+
     def warm_start(self, x0, y0):
         px, _, memx, kx = _ptr_stride(x0, self.n, self.batch, "x0")
         py, _, memy, ky = _ptr_stride(y0, self.m, self.batch, "y0")

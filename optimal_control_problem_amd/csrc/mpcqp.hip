@@ -56,6 +56,7 @@ struct DevIO {
   const double *x0, *y0, *rho0;
   double *x, *y, *z; int *status, *iters; double *info;
   double *ws; double *cscale; long long *dbg;
+  int reuse, keep;     // kept workspace: skip scaling + factorisation (mpcqp_update_vectors) / store the factor for that
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -1160,60 +1161,95 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   TS_DECL;
   for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
   if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
-  // ---- load: caller's CSC values -> ELL arrays. The block region of LDS is idle until the factorisation, so the
-  // ELL values of A, A', P live there for the whole scaling phase (host guarantees they fit) and are written to
-  // the HBM slab once, already scaled.
-  double *sA = GB ? valA : lds, *sAt = GB ? valAt : sA + pl.A.entries, *sP = GB ? valP : sAt + pl.At.entries;
-  for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
-  for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }
-  for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
-  for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
-  for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
-  bsync<NW>();
-  for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
-  bsync<NW>();
-
-  TS(0);
-  // ---- modified Ruiz equilibration: D in R, E in W, temporaries in X / Z
   double c = 1.0;
-  for (int it = 0; it < st.scaling; it++) {
-    for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
-      const int t = ch * WAVE + lane;
-      const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], lane);
-      const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], lane);
-      if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
+  int refactor = 1, prev_status = MPCQP_UNSOLVED;
+  if (io.reuse) {
+    // ---- kept workspace (mpcqp_update_vectors; OSQP's osqp_update_data_vec): P, A, their scaling D, E, c, the factor and rho
+    // stay from the previous solve of this instance; q, l, u are replaced and scaled with the kept D, E, c.  The factor is
+    // rebuilt only when a row changed between loose / inequality / equality, because rho_i depends on that class.
+    prev_status = io.status[b];
+    c = io.cscale[b];
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = Dg[t]; }
+    bsync<NW>();
+    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
+    bsync<NW>();
+    for (int t = tid; t < npad; t += NT) cx.Q[t] *= c * cx.R[t];
+    double chg[1] = {0.0};
+    for (int i = tid; i < mpad; i += NT) {
+      const double ei = Eg[i];
+      const double nl = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0, nu = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+      if (i < m) {
+        const double ol = lb[i], ou = ub[i];
+        const int oc = (ol < -Q_INFTY * Q_MIN_SCALING && ou > Q_INFTY * Q_MIN_SCALING) ? 0 : (ou - ol < Q_RHO_TOL ? 2 : 1);
+        const int nc = (nl < -Q_INFTY * Q_MIN_SCALING && nu > Q_INFTY * Q_MIN_SCALING) ? 0 : (nu - nl < Q_RHO_TOL ? 2 : 1);
+        if (oc != nc) chg[0] = 1.0;
+      }
+      lb[i] = nl; ub[i] = nu;
     }
-    ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+    block_combine<NW, 1, 0>(chg, cx.RED, wid, lane);
+    refactor = chg[0] != 0.0;
+    cx.c = c; cx.cinv = 1.0 / c;
+    if (!GB) {   // the factor blocks come back from the slab
+      const double *src = ws + pl.o_Lf;
+      for (long e = tid; e < (long)pl.nblk * BLK; e += NT) lds[e] = src[e];
+    }
     bsync<NW>();
-    for (int t = tid; t < npad; t += NT) cx.R[t] *= cx.X[t];
-    for (int i = tid; i < mpad; i += NT) cx.W[i] *= cx.Z[i];
+  } else {
+    // ---- load: caller's CSC values -> ELL arrays. The block region of LDS is idle until the factorisation, so the
+    // ELL values of A, A', P live there for the whole scaling phase (host guarantees they fit) and are written to
+    // the HBM slab once, already scaled.
+    double *sA = GB ? valA : lds, *sAt = GB ? valAt : sA + pl.A.entries, *sP = GB ? valP : sAt + pl.At.entries;
+    for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
+    for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }
+    for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
+    for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
     bsync<NW>();
-    double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
-    ell_rowmax_w<NW>(pl.P, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
-    block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
-    const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
-    c *= ct;
+    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
     bsync<NW>();
-  }
-  cx.c = c; cx.cinv = 1.0 / c;
-  TS(1);
-  // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
-  for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
-    const int i = ch * WAVE + lane; const double ei = cx.W[i];
-    for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
-  }
-  for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
-    const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
-    for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
-    for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
-  }
-  bsync<NW>();
-  for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
-  for (int i = tid; i < mpad; i += NT) {
-    const double ei = cx.W[i];
-    Eg[i] = ei;
-    lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
-    ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+
+    TS(0);
+    // ---- modified Ruiz equilibration: D in R, E in W, temporaries in X / Z
+    c = 1.0;
+    for (int it = 0; it < st.scaling; it++) {
+      for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+        const int t = ch * WAVE + lane;
+        const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], lane);
+        const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], lane);
+        if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
+      }
+      ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+      bsync<NW>();
+      for (int t = tid; t < npad; t += NT) cx.R[t] *= cx.X[t];
+      for (int i = tid; i < mpad; i += NT) cx.W[i] *= cx.Z[i];
+      bsync<NW>();
+      double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
+      ell_rowmax_w<NW>(pl.P, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+      block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
+      const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
+      c *= ct;
+      bsync<NW>();
+    }
+    cx.c = c; cx.cinv = 1.0 / c;
+    TS(1);
+    // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
+    for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+      const int i = ch * WAVE + lane; const double ei = cx.W[i];
+      for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
+    }
+    for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+      const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
+      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
+    }
+    bsync<NW>();
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
+    for (int i = tid; i < mpad; i += NT) {
+      const double ei = cx.W[i];
+      Eg[i] = ei;
+      lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
+      ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+    }
   }
   for (int t = tid; t < npad; t += NT) cx.X[t] = 0.0;
   for (int i = tid; i < mpad; i += NT) { cx.Z[i] = 0.0; cx.Y[i] = 0.0; }
@@ -1225,11 +1261,17 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
     bsync<NW>();
   }
-  cx.rho = fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
+  cx.rho = io.reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
   int status = MPCQP_UNSOLVED, iter_done = 0;
   Info in; memset(&in, 0, sizeof(in));
   TS(2);
-  const bool ok = factorize_res<NW>(cx);
+  bool ok = !(io.reuse && prev_status == MPCQP_NON_CVX);
+  if (ok && refactor) ok = factorize_res<NW>(cx);
+  else if (ok) {   // kept factor: only w = rho z - y, which the factorisation leaves behind otherwise
+    for (int i = tid; i < mpad; i += NT) cx.W[i] = i < m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
+    bsync<NW>();
+  }
   if (!ok) status = MPCQP_NON_CVX;
   TS(3);
 
@@ -1318,6 +1360,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     io.y[(long)b * m + i] = bad ? NAN : cx.cinv * Eg[i] * cx.Y[i];
     io.z[(long)b * m + i] = bad ? NAN : (1.0 / Eg[i]) * cx.Z[i];
   }
+  if (!GB && io.keep) {   // resident variants: park the factor in the slab for a following mpcqp_update_vectors solve
+    double *dst = ws + pl.o_Lf;
+    for (long e = tid; e < (long)pl.nblk * BLK; e += NT) dst[e] = lds[e];
+  }
   if (tid == 0) {
     io.status[b] = status; io.iters[b] = iter_done;
     io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
@@ -1377,6 +1423,7 @@ struct mpcqp_handle {
   double *ws = nullptr;
   double *dP = nullptr, *dq = nullptr, *dA = nullptr, *dl = nullptr, *du = nullptr;  // owned copies (host-memory updates)
   double *dx0 = nullptr, *dy0 = nullptr, *drho0 = nullptr;
+  bool keep = false, have_factor = false, reuse_next = false;
   double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
@@ -1597,7 +1644,7 @@ int mpcqp_update(mpcqp_handle *h, const double *P, long sP, const double *q, lon
     if ((rc = stage(h, &h->dl, l ? l : q, sl, h->m, &io.l, &io.sl))) return rc;
     if ((rc = stage(h, &h->du, u ? u : q, su, h->m, &io.u, &io.su))) return rc;
   } else return fail(MPCQP_ERR_ARG, "mem must be MPCQP_MEM_HOST or MPCQP_MEM_DEVICE");
-  h->have_data = true;
+  h->have_data = true; h->reuse_next = false;
   return MPCQP_OK;
 }
 
@@ -1610,6 +1657,35 @@ int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int me
   HIPCHK(hipMemcpy(h->dx0, x0, (size_t)h->batch * h->n * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->dy0, y0, (size_t)h->batch * h->m * sizeof(double), hipMemcpyHostToDevice));
   h->io.x0 = h->dx0; h->io.y0 = h->dy0;
+  return MPCQP_OK;
+}
+
+int mpcqp_keep_workspace(mpcqp_handle *h, int enable) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (enable && h->variant == 0) return fail(MPCQP_ERR_LIMIT, "the streaming kernel variant does not keep its workspace");
+  h->keep = enable != 0;
+  if (!h->keep) { h->have_factor = false; h->reuse_next = false; }
+  return MPCQP_OK;
+}
+
+int mpcqp_update_vectors(mpcqp_handle *h, const double *q, long sq, const double *l, long sl, const double *u, long su, int mem) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!h->keep || !h->have_factor)
+    return fail(MPCQP_ERR_STATE, "mpcqp_update_vectors needs mpcqp_keep_workspace(h, 1) and a completed mpcqp_update + mpcqp_solve before it");
+  if (!q || (h->m > 0 && (!l || !u))) return fail(MPCQP_ERR_ARG, "null data pointer");
+  if (sq < 0 || sl < 0 || su < 0 || (sq && sq < h->n) || (sl && sl < h->m) || (su && su < h->m)) return fail(MPCQP_ERR_ARG, "dimension mismatch: stride shorter than the array");
+  HIPCHK(hipSetDevice(h->device));
+  DevIO &io = h->io;
+  if (mem == MPCQP_MEM_DEVICE) {
+    io.q = q; io.sq = sq; io.l = l; io.sl = sl; io.u = u; io.su = su;
+  } else if (mem == MPCQP_MEM_HOST) {
+    if (h->last_stream || h->solved) HIPCHK(hipStreamSynchronize(h->last_stream));
+    int rc;
+    if ((rc = stage(h, &h->dq, q, sq, h->n, &io.q, &io.sq))) return rc;
+    if ((rc = stage(h, &h->dl, l ? l : q, sl, h->m, &io.l, &io.sl))) return rc;
+    if ((rc = stage(h, &h->du, u ? u : q, su, h->m, &io.u, &io.su))) return rc;
+  } else return fail(MPCQP_ERR_ARG, "mem must be MPCQP_MEM_HOST or MPCQP_MEM_DEVICE");
+  h->reuse_next = true;
   return MPCQP_OK;
 }
 
@@ -1633,6 +1709,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   DevIO io = h->io;
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   HIPCHK(hipEventRecord(h->ev0, s));
   if (h->gblocks && h->occ4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 4, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
   else if (h->gblocks) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
@@ -1644,7 +1721,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
-  h->last_stream = s; h->solved = true;
+  h->last_stream = s; h->solved = true; h->have_factor = h->keep;
   return MPCQP_OK;
 }
 

@@ -144,10 +144,39 @@ class CuCaQP:
         self.upperBound = v
         return True
 
+    # -- the reference's private update* members (CuCaQP.cpp:106-161; never called there).  Here they work: vectors go through
+    # the kept workspace (mpcqp_update_vectors: scaling, factorisation and rho stay), matrices force a full setup.
+    def updateHessianMatrix(self, hessian):
+        self._vectors_only = False
+        return self.setHessianMatrix(hessian)
+
+    def updateLinearConstraintsMatrix(self, A):
+        self._vectors_only = False
+        return self.setLinearConstraintsMatrix(A)
+
+    def _update_vec(self, setter, v):
+        if not self.isInitialized_:
+            return _err("Solver not initialized. Call initSolver() first.")          # CuCaQP.cpp:107-110 and siblings
+        if not setter(v):
+            return False
+        if self._qp is not None and self._result is not None and getattr(self, "_kept", False):
+            self._vectors_only = True
+        return True
+
+    def updateGradient(self, q):
+        return self._update_vec(self.setGradient, q)
+
+    def updateLowerBound(self, l):
+        return self._update_vec(self.setLowerBound, l)
+
+    def updateUpperBound(self, u):
+        return self._update_vec(self.setUpperBound, u)
+
     def setSystem(self, localSystem):
         """[P, q, A, l, u] (CuCaQP.cpp:271-288) or a models.LocalSystem; return values are dropped like the reference"""
         self.isInitialized_ = False
         self._result = None
+        self._vectors_only = False
         if hasattr(localSystem, "Pp"):
             ls = localSystem
             localSystem = [(ls.Pp, ls.Pi, ls.P), ls.q, (ls.Ap, ls.Ai, ls.A), ls.l, ls.u]
@@ -176,6 +205,11 @@ class CuCaQP:
                 self._qp = BatchQP(self.numOfVariables_, self.numOfConstraints_, self.batch, self._P[0], self._P[1],
                                    self._A[0], self._A[1], device=self._device, **kw)
                 self._pattern_key = key
+                self._kept = False
+                try:
+                    self._qp.keep_workspace(True); self._kept = True
+                except _lib.MpcqpError:
+                    pass                                  # streaming kernel variant: every solve is a full setup
             self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
             if self._start is not None:
                 self._qp.warm_start(self._start[0], self._start[1])
@@ -189,6 +223,9 @@ class CuCaQP:
         if not self.isInitialized_:
             return _err("Solver not initialized. Call initSolver() first.")
         try:
+            if getattr(self, "_vectors_only", False):
+                self._qp.update_vectors(self.gradient, self.lowerBound, self.upperBound)
+                self._vectors_only = False
             self._qp.solve()
             self._result = self._qp.get()
         except _lib.MpcqpError as e:

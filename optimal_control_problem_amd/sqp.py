@@ -116,11 +116,18 @@ class DeviceSQPOptimizationSolver:
         self.carry_rho = bool(options.get("carry_rho", False))
         # extension: an instance whose QP is infeasible keeps its iterate (the reference adds the NaN solution, :171-177)
         self.skip_failed_steps = bool(options.get("skip_failed_steps", False))
+        # extension (row f2): P and A do not depend on the iterate (linear dynamics, quadratic cost) -> after the first QP only
+        # q, l, u are replaced on the kept workspace (mpcqp_update_vectors): no equilibration, no factorisation.  The caller
+        # asserts the matrices are constant, exactly as with OSQP's osqp_update_data_vec.
+        self.constant_matrices = bool(options.get("constant_matrices", False))
+        self._kept = False
         self.batch = int(batch)
         self.ev = StageEvaluator(nlp, device=device, codegen=codegen)
         # reference SQPOptimizationSolver.cpp:80-85
         self.qp = BatchQP(self.ev.n, self.ev.m, self.batch, self.ev.Pp, self.ev.Pi, self.ev.Ap, self.ev.Ai,
                           eps_abs=1e-3, eps_rel=1e-3, max_iter=10000, warm_start=1 if self.warm_start_admm else 0, device=device)
+        if self.constant_matrices:
+            self.qp.keep_workspace(True)
         self.dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
         mk = lambda w, dt=torch.float64: torch.zeros((self.batch, w), dtype=dt, device=self.dev)
         self.x = mk(self.ev.nvar)                        # persists across calls like result_ (:88-91)
@@ -156,7 +163,11 @@ class DeviceSQPOptimizationSolver:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         for i in range(self.stepNum_):
             ev.eval(p, self.x, lbx, ubx, lbg, ubg, out=self.ls, stream=stream)
-            self.qp.update(self.ls["P"], self.ls["q"], self.ls["A"], self.ls["l"], self.ls["u"])
+            if self.constant_matrices and self._kept:
+                self.qp.update_vectors(self.ls["q"], self.ls["l"], self.ls["u"])
+            else:
+                self.qp.update(self.ls["P"], self.ls["q"], self.ls["A"], self.ls["l"], self.ls["u"])
+                self._kept = self.constant_matrices
             if self.warm_start_admm:
                 if self._have_start:
                     # after x += alpha * dx the remaining step is (1 - alpha) * dx; duals carry over

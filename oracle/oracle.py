@@ -52,6 +52,11 @@ def lib():
         L.orc_solve_batch_rho.restype = C.c_int
         L.orc_solve_batch_rho.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int] + \
             [C.c_void_p, C.c_long] * 5 + [C.c_void_p] * 9 + [C.c_int]
+        L.orc_state_create.restype = C.c_void_p
+        L.orc_state_create.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_int]
+        L.orc_state_destroy.argtypes = [C.c_void_p]
+        L.orc_state_solve.restype = C.c_int
+        L.orc_state_solve.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p, C.c_long] * 5 + [C.c_void_p] * 8 + [C.c_int]
         _LIB = L
     return _LIB
 
@@ -119,3 +124,53 @@ class Pattern:
             raise RuntimeError("orc_solve_batch failed rc=%d" % rc)
         return dict(x=x, y=y, z=z, status=status, iters=iters, obj=info[:, 0], prim_res=info[:, 1],
                     dual_res=info[:, 2], rho=info[:, 3])
+
+
+class State:
+    """Kept workspaces, one per instance (orc_state_*): solve() is a full setup + solve, solve_vectors() replaces q, l, u
+    only -- OSQP's osqp_update_data_vec on a kept workspace."""
+
+    def __init__(self, pattern, batch, settings=None):
+        self.pat, self.B = pattern, int(batch)
+        self.settings = settings or default_settings()
+        self.h = lib().orc_state_create(pattern.h, C.byref(self.settings), self.B)
+        if not self.h:
+            raise RuntimeError("orc_state_create failed")
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_state_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+    def _run(self, vectors_only, Px, q, Ax, l, u, x0, y0, nthreads):
+        B, n, m = self.B, self.pat.n, self.pat.m
+        def prep(a, width):
+            if a is None:
+                return None, 0
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.ndim == 1:
+                assert a.shape[0] == width
+                return a, 0
+            assert a.shape == (B, width), (a.shape, (B, width))
+            return a, width
+        Px, sP = prep(Px, int(self.pat.Pp[-1])); Ax, sA = prep(Ax, int(self.pat.Ap[-1]))
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(q, np.float64), (B, n)))
+        l = np.ascontiguousarray(np.broadcast_to(np.asarray(l, np.float64), (B, m)))
+        u = np.ascontiguousarray(np.broadcast_to(np.asarray(u, np.float64), (B, m)))
+        x = np.empty((B, n)); y = np.empty((B, m)); z = np.empty((B, m))
+        status = np.empty(B, np.int32); iters = np.empty(B, np.int32); info = np.empty((B, 4))
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, n); y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(B, m)
+        rc = lib().orc_state_solve(self.h, int(vectors_only), _p(Px), sP, _p(q), n, _p(Ax), sA, _p(l), m, _p(u), m,
+                                   _p(x0), _p(y0), _p(x), _p(y), _p(z), _p(status), _p(iters), _p(info), int(nthreads))
+        if rc != 0:
+            raise RuntimeError("orc_state_solve failed rc=%d" % rc)
+        return dict(x=x, y=y, z=z, status=status, iters=iters, obj=info[:, 0], prim_res=info[:, 1], dual_res=info[:, 2], rho=info[:, 3])
+
+    def solve(self, Px, q, Ax, l, u, x0=None, y0=None, nthreads=1):
+        return self._run(0, Px, q, Ax, l, u, x0, y0, nthreads)
+
+    def solve_vectors(self, q, l, u, x0=None, y0=None, nthreads=1):
+        return self._run(1, None, q, None, l, u, x0, y0, nthreads)

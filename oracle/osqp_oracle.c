@@ -500,23 +500,42 @@ static double rho_estimate(work_t *w) {
   return dmin(dmax(est, ORC_RHO_MIN), ORC_RHO_MAX);
 }
 
+/* reuse != 0: the workspace is kept from this instance's previous solve (osqp_update_data_vec semantics): P, A, D, E, c,
+ * rho and the factor stay; q, l, u are replaced and scaled with the kept D, E, c; the factor is rebuilt only if a row's
+ * class (loose / inequality / equality) changed, because rho_vec depends on it. */
 static void solve_one(work_t *w, const double *Px, const double *q, const double *Ax, const double *l, const double *u,
-                      const double *x0, const double *y0, double rho_start) {
+                      const double *x0, const double *y0, double rho_start, int reuse) {
   const orc_pattern *pt = w->pt; const orc_settings *st = w->st; int n = w->n, m = w->m;
-  /* [S1] load; clip bounds to +-OSQP_INFTY as osqp_setup does */
-  for (int k = 0; k < pt->nnzP; k++) w->P[k] = Px[pt->Pmap[k]];
-  for (int k = 0; k < pt->nnzA; k++) w->A[k] = Ax[k];
-  for (int j = 0; j < n; j++) w->q[j] = q[j];
-  for (int i = 0; i < m; i++) { w->l[i] = dmax(l[i], -ORC_INFTY); w->u[i] = dmin(u[i], ORC_INFTY); }
-  w->c = w->cinv = 1.0;
-  if (st->scaling) scale_data(w);
-  else { for (int j = 0; j < n; j++) w->D[j] = w->Dinv[j] = 1.0; for (int i = 0; i < m; i++) w->E[i] = w->Einv[i] = 1.0; }
-  w->rho = rho_start > 0.0 ? rho_start : st->rho;   /* a kept workspace carries rho over (osqp_update_* leave it alone) */
-  set_rho_vec(w, 1);
-  w->status = ORC_UNSOLVED; w->iter = 0; w->prim_res = w->dual_res = w->obj = 0.0;
-  for (int j = 0; j < n; j++) w->x[j] = w->xprev[j] = w->dx[j] = 0.0;
-  for (int i = 0; i < m; i++) w->z[i] = w->zprev[i] = w->y[i] = w->dy[i] = 0.0;
-  if (factor(w)) { w->status = ORC_NON_CVX; return; }
+  if (reuse) {
+    int prev_noncvx = (w->status == ORC_NON_CVX), changed = 0;
+    for (int j = 0; j < n; j++) w->q[j] = w->c * w->D[j] * q[j];
+    for (int i = 0; i < m; i++) { w->l[i] = w->E[i] * dmax(l[i], -ORC_INFTY); w->u[i] = w->E[i] * dmin(u[i], ORC_INFTY); }
+    for (int i = 0; i < m; i++) {
+      int ct = (w->l[i] < -ORC_INFTY * ORC_MIN_SCALING && w->u[i] > ORC_INFTY * ORC_MIN_SCALING) ? -1 : (w->u[i] - w->l[i] < ORC_RHO_TOL ? 1 : 0);
+      if (ct != w->ctype[i]) changed = 1;
+    }
+    w->iter = 0; w->prim_res = w->dual_res = w->obj = 0.0;
+    for (int j = 0; j < n; j++) w->x[j] = w->xprev[j] = w->dx[j] = 0.0;
+    for (int i = 0; i < m; i++) w->z[i] = w->zprev[i] = w->y[i] = w->dy[i] = 0.0;
+    if (prev_noncvx) return;
+    w->status = ORC_UNSOLVED;
+    if (changed) { set_rho_vec(w, 1); if (factor(w)) { w->status = ORC_NON_CVX; return; } }
+  } else {
+    /* [S1] load; clip bounds to +-OSQP_INFTY as osqp_setup does */
+    for (int k = 0; k < pt->nnzP; k++) w->P[k] = Px[pt->Pmap[k]];
+    for (int k = 0; k < pt->nnzA; k++) w->A[k] = Ax[k];
+    for (int j = 0; j < n; j++) w->q[j] = q[j];
+    for (int i = 0; i < m; i++) { w->l[i] = dmax(l[i], -ORC_INFTY); w->u[i] = dmin(u[i], ORC_INFTY); }
+    w->c = w->cinv = 1.0;
+    if (st->scaling) scale_data(w);
+    else { for (int j = 0; j < n; j++) w->D[j] = w->Dinv[j] = 1.0; for (int i = 0; i < m; i++) w->E[i] = w->Einv[i] = 1.0; }
+    w->rho = rho_start > 0.0 ? rho_start : st->rho;   /* a kept workspace carries rho over (osqp_update_* leave it alone) */
+    set_rho_vec(w, 1);
+    w->status = ORC_UNSOLVED; w->iter = 0; w->prim_res = w->dual_res = w->obj = 0.0;
+    for (int j = 0; j < n; j++) w->x[j] = w->xprev[j] = w->dx[j] = 0.0;
+    for (int i = 0; i < m; i++) w->z[i] = w->zprev[i] = w->y[i] = w->dy[i] = 0.0;
+    if (factor(w)) { w->status = ORC_NON_CVX; return; }
+  }
   if (st->warm_start && x0 && y0) { /* osqp_warm_start: scale x0 by Dinv, y0 by Einv * c, z = A x */
     for (int j = 0; j < n; j++) w->x[j] = x0[j] * w->Dinv[j];
     for (int i = 0; i < m; i++) w->y[i] = y0[i] * w->Einv[i] * w->c;
@@ -620,10 +639,48 @@ int orc_solve_batch_rho(const orc_pattern *pt, const orc_settings *st, int batch
 #endif
     for (int b = 0; b < batch; b++) {
       solve_one(w, Px + (size_t)b * sP, q + (size_t)b * sq, Ax + (size_t)b * sA, l + (size_t)b * sl, u + (size_t)b * su,
-                x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, rho0 ? rho0[b] : 0.0);
+                x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, rho0 ? rho0[b] : 0.0, 0);
       store(w, b, x, y, z, status, iters, info);
     }
     work_free(w);
   }
+  return 0;
+}
+
+/* ---- kept workspaces: one per instance, alive across solves (what OsqpEigen's solver object is between updates) */
+struct orc_state { const orc_pattern *pt; orc_settings st; int batch; work_t **w; int solved; };
+
+orc_state *orc_state_create(const orc_pattern *pt, const orc_settings *st, int batch) {
+  if (!pt || !st || batch <= 0) return NULL;
+  orc_state *s = (orc_state *)calloc(1, sizeof(orc_state));
+  s->pt = pt; s->st = *st; s->batch = batch; s->solved = 0;
+  s->w = (work_t **)calloc((size_t)batch, sizeof(work_t *));
+  for (int b = 0; b < batch; b++) s->w[b] = work_alloc(pt, &s->st);
+  return s;
+}
+
+void orc_state_destroy(orc_state *s) {
+  if (!s) return;
+  for (int b = 0; b < s->batch; b++) work_free(s->w[b]);
+  free(s->w); free(s);
+}
+
+int orc_state_solve(orc_state *s, int vectors_only,
+                    const double *Px, long sP, const double *q, long sq, const double *Ax, long sA,
+                    const double *l, long sl, const double *u, long su, const double *x0, const double *y0,
+                    double *x, double *y, double *z, int *status, int *iters, double *info, int nthreads) {
+  if (!s || (vectors_only && !s->solved)) return 1;
+  if (nthreads < 1) nthreads = 1;
+  const orc_pattern *pt = s->pt;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+#endif
+  for (int b = 0; b < s->batch; b++) {
+    work_t *w = s->w[b];
+    solve_one(w, vectors_only ? NULL : Px + (size_t)b * sP, q + (size_t)b * sq, vectors_only ? NULL : Ax + (size_t)b * sA,
+              l + (size_t)b * sl, u + (size_t)b * su, x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, 0.0, vectors_only);
+    store(w, b, x, y, z, status, iters, info);
+  }
+  s->solved = 1;
   return 0;
 }

@@ -104,6 +104,18 @@ int orc_solve_batch_rho(const orc_pattern *pat, const orc_settings *settings, in
                         double *x, double *y, double *z, int *status, int *iters, double *info,
                         int nthreads);
 
+/* Kept workspaces (one per instance): orc_state_solve(vectors_only = 0) is a full setup + solve that keeps every instance's
+ * scaled data, D, E, c, rho and factor; vectors_only = 1 replaces q, l, u only, as OSQP's osqp_update_data_vec does on a
+ * kept workspace (Px / Ax are ignored) -- the fast path of the reference's unused CuCaQP::update* members
+ * (reference src/sqp_solver/CuCaQP.cpp:106-161).  Returns nonzero if vectors_only is asked for before any full solve. */
+typedef struct orc_state orc_state;
+orc_state *orc_state_create(const orc_pattern *pat, const orc_settings *settings, int batch);
+void orc_state_destroy(orc_state *s);
+int orc_state_solve(orc_state *s, int vectors_only,
+                    const double *Px, long strideP, const double *q, long strideq, const double *Ax, long strideA,
+                    const double *l, long stridel, const double *u, long strideu, const double *x0, const double *y0,
+                    double *x, double *y, double *z, int *status, int *iters, double *info, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -341,3 +341,97 @@ def test_kernel_variants_hard_cases(built, monkeypatch, variant):
     got = qp.get(); qp.close()
     assert (got["iters"] == ref["iters"]).all()
     _close(got, ref, "x")
+
+
+# ---------------------------------------------------------------------------------------------- kept workspace
+@pytest.mark.parametrize("variant,name,B,N", [(None, "double_integrator", 24, 20), ("res1", "double_integrator", 24, 20),
+                                              ("gres4", "double_integrator", 24, 20), ("res4", "cartpole", 12, 30),
+                                              ("gres4", "quadrotor", 10, 10)])
+def test_kept_workspace_vectors_vs_oracle(built, monkeypatch, variant, name, B, N):
+    """mpcqp_keep_workspace + mpcqp_update_vectors (OSQP's osqp_update_data_vec on a kept workspace: scaling, factor and the
+    adapted rho stay) against the oracle's kept workspaces, on every kernel family: a full solve, a q/l/u-only solve, a
+    solve after a row changed from equality to inequality (factor rebuilt), and a return to the full path"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    if variant:
+        monkeypatch.setenv("MPCQP_VARIANT", variant)
+    mdl, ls, meta = models.make_workload(name, B, N=N)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    st = orc.State(pat, B, orc.default_settings())
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.keep_workspace(True)
+
+    def same(got, ref):
+        assert (got["status"] == ref["status"]).all(), (got["status"], ref["status"])
+        assert (got["iters"] == ref["iters"]).all(), (got["iters"], ref["iters"])
+        for k in ("x", "y", "z"):
+            _close(got, ref, k)
+        assert np.abs(got["rho"] - ref["rho"]).max() <= 1e-6 * np.abs(ref["rho"]).max()
+
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); same(qp.get(), st.solve(ls.P, ls.q, ls.A, ls.l, ls.u))
+    rng = np.random.default_rng(11)
+    frame0 = meta["frame0"].copy(); frame0[:, :mdl.nx] += rng.normal(0, 0.05, (B, mdl.nx))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    ls2 = mdl.local_system(meta["p"] + 0.1, meta["x_iterate"], lbx, ubx, lbg, ubg)       # same iterate -> same A, P; new q, l, u
+    assert np.array_equal(ls2.A, ls.A)
+    qp.update_vectors(ls2.q, ls2.l, ls2.u); qp.solve(); got2 = qp.get()
+    same(got2, st.solve_vectors(ls2.q, ls2.l, ls2.u))
+    # device pointers, and a class change in one row of every second instance
+    import torch
+    l3, u3 = ls2.l.copy(), ls2.u.copy()
+    l3[::2, mdl.np + 1] -= 0.25; u3[::2, mdl.np + 1] += 0.25
+    dq, dl, du = [torch.as_tensor(a, device="cuda") for a in (ls2.q, l3, u3)]
+    qp.update_vectors(dq, dl, du); qp.solve(); same(qp.get(), st.solve_vectors(ls2.q, l3, u3))
+    # back to a full setup
+    qp.update(ls2.P, ls2.q, ls2.A, ls2.l, ls2.u); qp.solve(); same(qp.get(), st.solve(ls2.P, ls2.q, ls2.A, ls2.l, ls2.u))
+    qp.close()
+
+
+def test_kept_workspace_errors_and_nonconvex(built, monkeypatch):
+    from optimal_control_problem_amd import _lib
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("double_integrator", 4)
+    qp = BatchQP(ls.n, ls.m, 4, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    with pytest.raises(_lib.MpcqpError) as e:
+        qp.update_vectors(ls.q, ls.l, ls.u)                      # keep_workspace not enabled
+    assert e.value.code == _lib.ERR_STATE
+    qp.keep_workspace(True)
+    with pytest.raises(_lib.MpcqpError) as e:
+        qp.update_vectors(ls.q, ls.l, ls.u)                      # no kept solve yet
+    assert e.value.code == _lib.ERR_STATE
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); qp.get()
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        qp.update_vectors(ls.q[:, :-1], ls.l, ls.u)
+    # an instance with an indefinite P stays non-convex through vector updates; the others keep solving
+    P = ls.P.copy(); P[1] = -np.abs(P[1]) - 1.0
+    qp.update(P, ls.q, ls.A, ls.l, ls.u); qp.solve(); a = qp.get()
+    qp.update_vectors(ls.q * 0.5, ls.l, ls.u); qp.solve(); b = qp.get()
+    assert a["status"][1] == 9 and b["status"][1] == 9 and np.isnan(b["x"][1]).all()
+    assert (np.delete(b["status"], 1) == 1).all()
+    qp.close()
+    monkeypatch.setenv("MPCQP_VARIANT", "stream")
+    qs = BatchQP(ls.n, ls.m, 4, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    with pytest.raises(_lib.MpcqpError) as e:
+        qs.keep_workspace(True)
+    assert e.value.code == _lib.ERR_LIMIT
+    qs.close()
+
+
+def test_cucaqp_update_members_use_the_kept_workspace(built):
+    """the reference's private update* members (CuCaQP.cpp:106-161), working: updateGradient / updateLowerBound / updateUpperBound
+    + solve() re-solve without a new setup and agree with the oracle's kept workspace"""
+    from optimal_control_problem_amd.cucaqp import CuCaQP
+    from oracle import oracle as orc
+    B = 6
+    mdl, ls, meta = models.make_workload("double_integrator", B)
+    qp = CuCaQP(batch=B); qp.setDimension(ls.n, ls.m)
+    assert qp.updateGradient(ls.q) is False                      # "Solver not initialized" (CuCaQP.cpp:118-121)
+    qp.setSystem(ls); assert qp.initSolver() and qp.solve()
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
+    st.solve(ls.P, ls.q, ls.A, ls.l, ls.u)
+    q2 = ls.q * 1.3; l2 = ls.l - 0.01; u2 = ls.u + 0.01
+    assert qp.updateGradient(q2) and qp.updateLowerBound(l2) and qp.updateUpperBound(u2) and qp.solve()
+    ref = st.solve_vectors(q2, l2, u2)
+    assert (qp.getIterations() == ref["iters"]).all() and np.abs(qp.getSolution() - ref["x"]).max() < 1e-6
+    assert qp.updateGradient(np.zeros(3)) is False               # size mismatch
+    qp.close()

@@ -181,3 +181,26 @@ def test_facade_with_custom_dynamics_runs_device_resident(built):
         assert type(ocp.OSQPSolverPtr_).__name__ == ("DeviceSQPOptimizationSolver" if flag == "true" else "SQPOptimizationSolver")
     assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
     assert np.abs(res["true"][:, :4] - frame).max() < 5e-3
+
+
+def test_device_sqp_constant_matrices_matches_oracle_kept_workspace(built):
+    """linear MPC ticks on the kept workspace (mpcqp_update_vectors): the device loop with constant_matrices against the same
+    sequence of QPs on the oracle's kept workspaces"""
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver
+    from oracle import oracle as orc
+    B = 12
+    mdl, ls, meta = models.make_workload("double_integrator", B)
+    dev = DeviceSQPOptimizationSolver(mdl, {"max_iter": 1, "alpha": 1.0, "constant_matrices": True}, batch=B)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
+    arg = dict(lbx=meta["lbx"].copy(), ubx=meta["ubx"].copy(), lbg=meta["lbg"], ubg=meta["ubg"], p=meta["p"])
+    x = np.zeros((B, mdl.nvar)); rng = np.random.default_rng(2)
+    for tick in range(4):
+        sys_ = mdl.local_system(meta["p"], x, arg["lbx"], arg["ubx"], arg["lbg"], arg["ubg"])
+        ref = st.solve(sys_.P, sys_.q, sys_.A, sys_.l, sys_.u) if tick == 0 else st.solve_vectors(sys_.q, sys_.l, sys_.u)
+        got = dev.getOptimalSolution(arg)
+        x = x + ref["x"][:, mdl.np:]
+        assert (dev.iters.cpu().numpy() == ref["iters"]).all()
+        assert np.abs(got["x"] - x).max() <= 1e-6 * (1 + np.abs(x).max())
+        s0 = arg["lbx"][:, :mdl.nx] + rng.normal(0, 0.05, (B, mdl.nx))
+        arg["lbx"][:, :mdl.nx] = s0; arg["ubx"][:, :mdl.nx] = s0
+    dev.close()

@@ -64,3 +64,37 @@ def test_oracle_threads_and_shared_matrices(built):
     a = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, nthreads=1)
     b = pat.solve(ls.P[0], ls.q, ls.A[0], ls.l, ls.u, nthreads=4)
     assert (a["iters"] == b["iters"]).all() and np.array_equal(a["x"], b["x"])
+
+
+def test_kept_workspace_vector_updates(built):
+    """orc_state_*: replacing q, l, u on a kept workspace (OSQP's osqp_update_data_vec) -- the kept scaling / factor / rho give a
+    valid solve of the NEW problem (checked against a fresh high-accuracy solve), also when rows change between equality and
+    inequality (factor rebuilt), and asking for it before any full solve is an error"""
+    from oracle import oracle as orc
+    from optimal_control_problem_amd import models
+    mdl, ls, meta = models.make_workload("double_integrator", 6)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    st = orc.State(pat, ls.batch, orc.default_settings())
+    with pytest.raises(RuntimeError):
+        st.solve_vectors(ls.q, ls.l, ls.u)
+    first = st.solve(ls.P, ls.q, ls.A, ls.l, ls.u)
+    plain = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings())
+    assert np.array_equal(first["x"], plain["x"]) and np.array_equal(first["iters"], plain["iters"])
+    # new initial states: only l, u change (first frame pinned elsewhere)
+    rng = np.random.default_rng(4)
+    frame0 = meta["frame0"].copy(); frame0[:, :2] += rng.normal(0, 0.3, (ls.batch, 2))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    ls2 = mdl.local_system(meta["p"], meta["x_iterate"], lbx, ubx, lbg, ubg)
+    assert np.array_equal(ls2.A, ls.A) and np.array_equal(ls2.P, ls.P)
+    kept = st.solve_vectors(ls2.q, ls2.l, ls2.u)
+    tight = pat.solve(ls2.P, ls2.q, ls2.A, ls2.l, ls2.u, orc.default_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000))
+    assert (kept["status"] == 1).all() and np.abs(kept["x"] - tight["x"]).max() < 0.3
+    assert (kept["rho"] == first["rho"]).all() or (kept["iters"] > 0).all()
+    assert kept["iters"].mean() < first["iters"].mean()                      # the adapted rho is already in place
+    # a row class change: release the velocity pin of frame 0 into an inequality
+    l3, u3 = ls2.l.copy(), ls2.u.copy()
+    row = mdl.np + 1
+    l3[:, row] -= 0.5; u3[:, row] += 0.5
+    kept3 = st.solve_vectors(ls2.q, l3, u3)
+    tight3 = pat.solve(ls2.P, ls2.q, ls2.A, l3, u3, orc.default_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000))
+    assert (kept3["status"] == 1).all() and np.abs(kept3["x"] - tight3["x"]).max() < 0.3

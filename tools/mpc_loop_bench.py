@@ -22,7 +22,8 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 mdl, ls, meta = models.make_workload("double_integrator", B)
 nx, nu, f, N, h = mdl.nx, mdl.nu, mdl.f, mdl.N, mdl.dt
 out = {"workload": "double_integrator N=%d batch=%d, %d closed-loop ticks (1 QP per tick)" % (N, B, T)}
-for label, opt in (("_process_warmup", {}), ("cold", {}), ("warm", {"warm_start_admm": True}), ("warm+rho", {"warm_start_admm": True, "carry_rho": True})):
+for label, opt in (("_process_warmup", {}), ("cold", {}), ("warm", {"warm_start_admm": True}), ("warm+rho", {"warm_start_admm": True, "carry_rho": True}),
+                   ("kept workspace", {"constant_matrices": True}), ("kept workspace+warm", {"constant_matrices": True, "warm_start_admm": True})):
     dev = DeviceSQPOptimizationSolver(mdl, dict({"max_iter": 1, "alpha": 1.0, "skip_failed_steps": True}, **opt), batch=B)
     arg = {k: torch.as_tensor(meta[k], dtype=torch.float64, device="cuda") for k in ("lbx", "ubx", "lbg", "ubg", "p")}
     state = torch.as_tensor(meta["frame0"][:, :nx], dtype=torch.float64, device="cuda").clone()
