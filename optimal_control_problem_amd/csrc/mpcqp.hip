@@ -1021,8 +1021,9 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
   });
   // P x and A' y land on the same rows for a given wave (both chunked by wid), so no barrier is needed in between
   for (int c = wid; c < pl.P.nchunks; c += NW) {
-    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, pl.P.chunk_off[c], pl.P.chunk_off[c + 1], lane);
-    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, pl.At.chunk_off[c], pl.At.chunk_off[c + 1], lane);
+    const int la = lane;
+    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, pl.P.chunk_off[c], pl.P.chunk_off[c + 1], la);
+    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, pl.At.chunk_off[c], pl.At.chunk_off[c + 1], la);
     const int t = c * WAVE + lane;
     if (t < pl.npad) {
       const double dinv = unscale ? 1.0 / Dg[t] : 1.0, qv = cx.Q[t], du = qv + px + aty;
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 // CU anyway (the kernel may then use the whole register file), 2 otherwise
 // GB = the factor blocks stay in the per-QP HBM slab (factors that do not fit LDS); LDS then holds only the temp
 // tiles, the ADMM vectors and the schedule, and the segment loops keep several blocks in flight.
-template <int NW, int MINW, bool GB>
+template <int NW, int MINW, bool GB, bool REUSE>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
@@ -1163,7 +1164,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
   double c = 1.0;
   int refactor = 1, prev_status = MPCQP_UNSOLVED;
-  if (io.reuse) {
+  constexpr bool REUSE_T = REUSE;
+  const bool reuse = REUSE_T && io.reuse;
+  if (reuse) {
     // ---- kept workspace (mpcqp_update_vectors; OSQP's osqp_update_data_vec): P, A, their scaling D, E, c, the factor and rho
     // stay from the previous solve of this instance; q, l, u are replaced and scaled with the kept D, E, c.  The factor is
     // rebuilt only when a row changed between loose / inequality / equality, because rho_i depends on that class.
@@ -1214,8 +1217,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     for (int it = 0; it < st.scaling; it++) {
       for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
         const int t = ch * WAVE + lane;
-        const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], lane);
-        const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], lane);
+        const int la = lane;
+        const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], la);
+        const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], la);
         if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
       }
       ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
@@ -1262,11 +1266,11 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     bsync<NW>();
   }
   // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
-  cx.rho = io.reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  cx.rho = reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
   int status = MPCQP_UNSOLVED, iter_done = 0;
   Info in; memset(&in, 0, sizeof(in));
   TS(2);
-  bool ok = !(io.reuse && prev_status == MPCQP_NON_CVX);
+  bool ok = !(reuse && prev_status == MPCQP_NON_CVX);
   if (ok && refactor) ok = factorize_res<NW>(cx);
   else if (ok) {   // kept factor: only w = rho z - y, which the factorisation leaves behind otherwise
     for (int i = tid; i < mpad; i += NT) cx.W[i] = i < m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
@@ -1459,6 +1463,17 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
   return MPCQP_OK;
 }
 
+// the kernel instance a handle runs: waves per QP, register budget, factor location, and -- as its own instance so that the
+// full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
+template <bool REUSE>
+static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
+  if (h->variant == 1) return (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
+  if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
+  return h->wide ? (const void *)mpcqp_res_kernel<4, 1, false, REUSE> : (const void *)mpcqp_res_kernel<4, 2, false, REUSE>;
+}
+static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) { return reuse ? res_kernel_pick<true>(h) : res_kernel_pick<false>(h); }
+
 extern "C" {
 
 void mpcqp_default_settings(mpcqp_settings *s) {
@@ -1597,11 +1612,11 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
 #undef UP
   h->wide = h->variant == 4 && h->lds > 80 * 1024;
   if (h->lds > 48 * 1024) {
-    const void *fn = h->gblocks ? (h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true> : (const void *)mpcqp_res_kernel<4, 2, true>)
-                     : h->variant == 1 ? (const void *)mpcqp_res_kernel<1, 2, false> : h->variant == 4 ? (h->wide ? (const void *)mpcqp_res_kernel<4, 1, false> : (const void *)mpcqp_res_kernel<4, 2, false>)
-                     : h->variant == 8 ? (const void *)mpcqp_res_kernel<8, 2, false> : (h->lds > 40 * 1024 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
-      return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
+    const void *fns[2] = {res_kernel_of(h, false), res_kernel_of(h, true)};
+    if (h->variant == 0) fns[0] = fns[1] = h->lds > 40 * 1024 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>;
+    for (const void *fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
+        return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
   }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
@@ -1711,12 +1726,10 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   HIPCHK(hipEventRecord(h->ev0, s));
-  if (h->gblocks && h->occ4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 4, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->gblocks) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2, true>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 1) hipLaunchKernelGGL((mpcqp_res_kernel<1, 2, false>), dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 4 && h->wide) hipLaunchKernelGGL((mpcqp_res_kernel<4, 1, false>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 4) hipLaunchKernelGGL((mpcqp_res_kernel<4, 2, false>), dim3(h->batch), dim3(4 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
-  else if (h->variant == 8) hipLaunchKernelGGL((mpcqp_res_kernel<8, 2, false>), dim3(h->batch), dim3(8 * WAVE), (size_t)h->lds, s, h->dp, h->dres, h->st, io);
+  if (h->variant > 0) {
+    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
+    HIPCHK(hipLaunchKernel(res_kernel_of(h, io.reuse != 0), dim3(h->batch), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
+  }
   else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
