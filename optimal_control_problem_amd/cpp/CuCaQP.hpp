@@ -88,6 +88,23 @@ class CuCaQP {
     setLowerBound(l, numOfConstraints_); setUpperBound(u, numOfConstraints_);
   }
 
+  // The reference's private update* members (CuCaQP.h:93-101, CuCaQP.cpp:106-161; never called there).  Vectors go through the
+  // kept workspace (mpcqp_update_vectors = OSQP's osqp_update_data_vec: scaling, factorisation and rho stay, the next solve()
+  // skips the setup); a matrix update falls back to a full setup at the next solve().
+  bool updateHessianMatrix(const CscView &P) {
+    if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
+    vectorsOnly_ = false; matricesDirty_ = true;
+    return setHessianMatrix(P);
+  }
+  bool updateLinearConstraintsMatrix(const CscView &A) {
+    if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
+    vectorsOnly_ = false; matricesDirty_ = true;
+    return setLinearConstraintsMatrix(A);
+  }
+  bool updateGradient(const double *q, int size) { return updateVector(setGradient(q, size)); }
+  bool updateLowerBound(const double *l, int size) { return updateVector(setLowerBound(l, size)); }
+  bool updateUpperBound(const double *u, int size) { return updateVector(setUpperBound(u, size)); }
+
   bool initSolver() {                                            // reference CuCaQP.cpp:183-197
     isInitialized_ = false;
     if (Pp_.empty() || Ap_.empty() || q_.empty() || l_.empty() || u_.empty()) { std::cerr << "Error: Failed to initialize solver." << std::endl; return false; }
@@ -96,7 +113,9 @@ class CuCaQP {
       clearSolver();
       rc = mpcqp_create(numOfVariables_, numOfConstraints_, batch_, Pp_.data(), Pi_.data(), Ap_.data(), Ai_.data(), &settings_, &handle_);
       patternChanged_ = dirty_ = false;
+      kept_ = rc == MPCQP_OK && mpcqp_keep_workspace(handle_, 1) == MPCQP_OK;   // not on the streaming kernel variant
     }
+    vectorsOnly_ = matricesDirty_ = false; solvedOnce_ = false;
     if (rc == MPCQP_OK)
       rc = mpcqp_update(handle_, Pv_.data(), (long)Pi_.size(), q_.data(), numOfVariables_, Av_.data(), (long)Ai_.size(),
                         l_.data(), numOfConstraints_, u_.data(), numOfConstraints_, MPCQP_MEM_HOST);
@@ -107,7 +126,15 @@ class CuCaQP {
 
   bool solve() {                                                 // reference CuCaQP.cpp:199-211
     if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
-    int rc = mpcqp_solve(handle_, nullptr);
+    int rc = MPCQP_OK;
+    if (vectorsOnly_ && kept_ && solvedOnce_ && !matricesDirty_)
+      rc = mpcqp_update_vectors(handle_, q_.data(), numOfVariables_, l_.data(), numOfConstraints_, u_.data(), numOfConstraints_, MPCQP_MEM_HOST);
+    else if (vectorsOnly_ || matricesDirty_)
+      rc = mpcqp_update(handle_, Pv_.data(), (long)Pi_.size(), q_.data(), numOfVariables_, Av_.data(), (long)Ai_.size(),
+                        l_.data(), numOfConstraints_, u_.data(), numOfConstraints_, MPCQP_MEM_HOST);
+    vectorsOnly_ = matricesDirty_ = false;
+    if (rc == MPCQP_OK) rc = mpcqp_solve(handle_, nullptr);
+    solvedOnce_ = rc == MPCQP_OK;
     solution_.resize((size_t)batch_ * numOfVariables_); status_.resize(batch_); iters_.resize(batch_);
     if (rc == MPCQP_OK) rc = mpcqp_get(handle_, solution_.data(), nullptr, nullptr, status_.data(), iters_.data(), nullptr, MPCQP_MEM_HOST);
     if (rc != MPCQP_OK) { std::cerr << "Error: Failed to solve problem. Error code: " << rc << std::endl; return false; }
@@ -148,9 +175,15 @@ class CuCaQP {
     return changed;
   }
   void clearSolver() { if (handle_) { mpcqp_destroy(handle_); handle_ = nullptr; } isInitialized_ = false; }
+  bool updateVector(bool stored) {
+    if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }   // CuCaQP.cpp:118-121
+    if (stored) vectorsOnly_ = true;
+    return stored;
+  }
 
   int batch_ = 1, numOfVariables_ = 0, numOfConstraints_ = 0;
   bool isInitialized_ = false, verbose_ = false, patternChanged_ = true, dirty_ = false;
+  bool kept_ = false, vectorsOnly_ = false, matricesDirty_ = false, solvedOnce_ = false;
   mpcqp_settings settings_;
   mpcqp_handle *handle_ = nullptr;
   std::vector<int> Pp_, Pi_, Ap_, Ai_, status_, iters_;

@@ -20,5 +20,16 @@ int main() {
   if (!qp.solve()) return 1;
   const auto &x = qp.getSolution();
   std::printf("x = %.6f %.6f status %d iters %d\n", x[0], x[1], qp.getStatus()[0], qp.getIterations()[0]);
-  return (std::fabs(x[0] - 0.5) < 5e-3 && std::fabs(x[1] - 0.5) < 5e-3 && qp.getStatus()[0] == MPCQP_SOLVED) ? 0 : 1;
+  if (!(std::fabs(x[0] - 0.5) < 5e-3 && std::fabs(x[1] - 0.5) < 5e-3 && qp.getStatus()[0] == MPCQP_SOLVED)) return 1;
+  // the update* members (reference CuCaQP.cpp:106-161): new gradient and bounds on the kept workspace -> min (x1-1)^2 + x2^2 on
+  // x1 + x2 = 2 is (1.5, 0.5); then a Hessian update (full setup again): 4 x1^2 + 2 x2^2 - 2 x1 -> (5/6, 7/6)
+  const double q2[] = {-2, 0}, l2[] = {-50, -100, 2}, u2[] = {50, 100, 2};
+  if (!qp.updateGradient(q2, 2) || !qp.updateLowerBound(l2, 3) || !qp.updateUpperBound(u2, 3) || !qp.solve()) return 1;
+  std::printf("x = %.6f %.6f status %d iters %d\n", x[0], x[1], qp.getStatus()[0], qp.getIterations()[0]);
+  if (!(std::fabs(x[0] - 1.5) < 5e-3 && std::fabs(x[1] - 0.5) < 5e-3)) return 1;
+  if (qp.updateGradient(q2, 3)) return 1;                   // size mismatch must be refused (CuCaQP.cpp:122-126)
+  const double Pv2[] = {8.0, 4.0};
+  if (!qp.updateHessianMatrix({2, 2, Pp, Pi, Pv2}) || !qp.solve()) return 1;
+  std::printf("x = %.6f %.6f status %d iters %d\n", x[0], x[1], qp.getStatus()[0], qp.getIterations()[0]);
+  return (std::fabs(x[0] - 5.0 / 6.0) < 5e-3 && std::fabs(x[1] - 7.0 / 6.0) < 5e-3) ? 0 : 1;
 }
