@@ -160,7 +160,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s nx=%d nu=%d horizon=%d, reference formulation n=%d m=%d, batch=%d per GPU, "
                                    "eps_abs=eps_rel=1e-3, cold start" % (mdl.name, mdl.nx, mdl.nu, N, ls.n, ls.m, batch),
-                       "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "dispatch": "longest-first by the previous solve's ADMM iteration counts (scheduling hint, results unchanged)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # the same launch priced on its measured HBM traffic instead of the algorithmic bytes
@@ -177,6 +178,18 @@ def main():
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
         if world == 1 and not args.force_iters:
+            # the same step with the dispatch hint off (instances handed to workgroups in batch order, as a first solve on a
+            # fresh handle does): separates the kernel from the scheduling gain.  `value` is the default behaviour (hint on).
+            qp.set_dispatch_hint(False)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(); tn = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize(); tn = (time.perf_counter() - tn) / 5
+            out["in_order_dispatch"] = {"value": batch / tn, "unit": "QP solves/s", "ms_per_step": tn * 1e3,
+                                        "note": "mpcqp_set_dispatch_hint(h, 0): no longest-first ordering from the previous solve's iteration counts"}
+            qp.set_dispatch_hint(True)
             # the same step with the boundary handing over HOST buffers (what a CuCaQP-style caller does: pageable inputs in,
             # x / status / iters out): H2D + kernel + D2H per step.  Reported beside `value`, never as `value`.
             hx = np.empty((batch, ls.n)); hst = np.empty(batch, np.int32); hit = np.empty(batch, np.int32)

@@ -114,6 +114,14 @@ int mpcqp_set_rho(mpcqp_handle *h, const double *rho0, int mem);
  * Asynchronous: returns after the launch; results are ordered on `stream`. */
 int mpcqp_solve(mpcqp_handle *h, void *stream);
 
+/* Scheduling hint (on by default; MPCQP_NO_LPT=1 in the environment turns it off at create): after every solve the instances
+ * are ranked by their ADMM iteration count, and the next solve on the handle hands them to workgroups in that order, longest
+ * first.  Instances are independent, so no output changes by a bit; what changes is the tail of the launch -- with one QP per
+ * workgroup and 25- and 100-iteration instances mixed, in-order dispatch leaves CUs idle while the last long instance
+ * finishes.  The predictor is exact when the same batch is solved again and good in an MPC loop (consecutive solves of the
+ * same plants); a stale hint is harmless.  No reference counterpart (the reference solves one QP at a time). */
+int mpcqp_set_dispatch_hint(mpcqp_handle *h, int enable);
+
 /* Replaces CuCaQP::getSolution / getSolutionAsDM (CuCaQP.cpp:213-224), and additionally surfaces what the
  * reference drops: duals y, row activities z, per-QP status, iteration count and
  * info[4] = {objective, primal residual, dual residual, final rho}.  Any output pointer may be NULL.

@@ -86,6 +86,10 @@ class BatchQP:
             args += [ptr, stride]
         _lib.check(_lib.lib().mpcqp_update(self._h, *args, mems.pop()))
 
+    def set_dispatch_hint(self, enable=True):
+        """longest-first dispatch order from the previous solve's iteration counts (on by default; changes no result)"""
+        _lib.check(_lib.lib().mpcqp_set_dispatch_hint(self._h, 1 if enable else 0))
+
     def keep_workspace(self, enable=True):
         """keep scaling, factorisation and rho across solves so that update_vectors() can skip the setup"""
         _lib.check(_lib.lib().mpcqp_keep_workspace(self._h, 1 if enable else 0))

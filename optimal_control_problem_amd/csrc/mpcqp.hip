@@ -56,6 +56,7 @@ struct DevIO {
   const double *x0, *y0, *rho0;
   double *x, *y, *z; int *status, *iters; double *info;
   double *ws; double *cscale; long long *dbg;
+  const int *order;    // dispatch order: workgroup g solves instance order[g] (NULL = identity); see mpcqp_order_kernel
   int reuse, keep;     // kept workspace: skip scaling + factorisation (mpcqp_update_vectors) / store the factor for that
 };
 
@@ -439,7 +440,7 @@ __device__ int check_termination(Ctx &cx, Info &in, int approximate) {
 template <int PD>
 __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = io.order ? io.order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
   Ctx cx;
   cx.pl = &pl; cx.st = &st;
   cx.X = lds; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
@@ -1139,7 +1140,8 @@ template <int NW, int MINW, bool GB, bool REUSE>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   RCtx cx;
   cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
@@ -1393,6 +1395,24 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_blockops_kernel(const d
   if (lane == 0) *fail = ok ? 0 : 1;
 }
 
+// Dispatch hint for the NEXT solve on a handle: instances ordered by descending iteration count of the solve that just
+// finished (counting sort over iters / unit).  Instances are independent, so the order changes no result -- it only lets the
+// long ones start first instead of wherever they sit in the batch: with one QP per workgroup and 25 / 50 / 75-iteration
+// instances mixed, the in-order tail leaves CUs idle while the last long instance finishes (longest-processing-time-first
+// scheduling; in an MPC loop consecutive solves of the same plants have correlated iteration counts).
+__global__ void __launch_bounds__(1024) mpcqp_order_kernel(const int *__restrict__ iters, int *__restrict__ order, int batch, int unit) {
+  constexpr int NB = 256;
+  __shared__ int start[NB];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < NB; k += blockDim.x) start[k] = 0;
+  __syncthreads();
+  for (int i = tid; i < batch; i += blockDim.x) atomicAdd(&start[min(max(iters[i], 0) / unit, NB - 1)], 1);
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = NB - 1; k >= 0; k--) { const int c = start[k]; start[k] = acc; acc += c; } }
+  __syncthreads();
+  for (int i = tid; i < batch; i += blockDim.x) order[atomicAdd(&start[min(max(iters[i], 0) / unit, NB - 1)], 1)] = i;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
@@ -1428,6 +1448,7 @@ struct mpcqp_handle {
   double *dP = nullptr, *dq = nullptr, *dA = nullptr, *dl = nullptr, *du = nullptr;  // owned copies (host-memory updates)
   double *dx0 = nullptr, *dy0 = nullptr, *drho0 = nullptr;
   bool keep = false, have_factor = false, reuse_next = false;
+  int *order[2] = {nullptr, nullptr}; int order_cur = -1; bool lpt = true; hipEvent_t ev_order = nullptr;   // dispatch hint, double-buffered
   double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
@@ -1620,6 +1641,12 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
+  h->lpt = !getenv("MPCQP_NO_LPT");
+  {   // dispatch-hint buffers up front: nothing is allocated inside mpcqp_solve, so a solve can be captured in a HIP graph
+    int rc;
+    if ((rc = dalloc(h, &h->order[0], (size_t)batch)) || (rc = dalloc(h, &h->order[1], (size_t)batch))) return bail(rc);
+    if (hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
+  }
   *out = h;
   return MPCQP_OK;
 }
@@ -1675,6 +1702,13 @@ int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int me
   return MPCQP_OK;
 }
 
+int mpcqp_set_dispatch_hint(mpcqp_handle *h, int enable) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  h->lpt = enable != 0;
+  if (!h->lpt) h->order_cur = -1;
+  return MPCQP_OK;
+}
+
 int mpcqp_keep_workspace(mpcqp_handle *h, int enable) {
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
   if (enable && h->variant == 0) return fail(MPCQP_ERR_LIMIT, "the streaming kernel variant does not keep its workspace");
@@ -1725,6 +1759,8 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   DevIO io = h->io;
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
+  io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
+  if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
   HIPCHK(hipEventRecord(h->ev0, s));
   if (h->variant > 0) {
     void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
@@ -1734,6 +1770,13 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
+  if (h->lpt && h->batch > 1) {   // order of the next solve from this solve's iteration counts
+    const int nxt = h->order_cur == 0 ? 1 : 0;
+    hipLaunchKernelGGL(mpcqp_order_kernel, dim3(1), dim3(1024), 0, s, (const int *)h->oiters, h->order[nxt], h->batch, std::max(1, h->st.check_termination));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_order, s));
+    h->order_cur = nxt;
+  }
   h->last_stream = s; h->solved = true; h->have_factor = h->keep;
   return MPCQP_OK;
 }
@@ -1769,6 +1812,7 @@ void mpcqp_destroy(mpcqp_handle *h) {
   for (void *p : h->dev_allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   delete h;
 }
 

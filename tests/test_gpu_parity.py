@@ -435,3 +435,24 @@ def test_cucaqp_update_members_use_the_kept_workspace(built):
     assert (qp.getIterations() == ref["iters"]).all() and np.abs(qp.getSolution() - ref["x"]).max() < 1e-6
     assert qp.updateGradient(np.zeros(3)) is False               # size mismatch
     qp.close()
+
+
+def test_dispatch_hint_changes_no_result(built):
+    """the longest-first dispatch order (taken from the previous solve's iteration counts) only permutes which workgroup takes
+    which instance: bitwise identical outputs with a fresh handle (identity order), with its own history, and with the
+    history of a different batch"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    B = 700
+    mdl, ls, _ = models.make_workload("double_integrator", B)          # 25 .. 125 iterations: a strongly mixed batch
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); first = qp.get()
+    assert len(np.unique(first["iters"])) >= 3
+    qp.solve(); second = qp.get()                                      # now ordered by first["iters"]
+    for k in ("x", "y", "z", "status", "iters", "rho"):
+        assert np.array_equal(first[k], second[k], equal_nan=True), k
+    perm = np.random.default_rng(0).permutation(B)                     # other data: the kept hint is stale, results must not care
+    qp.update(ls.P, ls.q[perm], ls.A, ls.l[perm], ls.u[perm]); qp.solve(); third = qp.get()
+    assert np.array_equal(third["x"], first["x"][perm]) and np.array_equal(third["iters"], first["iters"][perm])
+    qp.close()
+    ref = problems.oracle_solve(models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[:64], ls.q[:64], ls.A[:64], ls.l[:64], ls.u[:64]))
+    assert (first["iters"][:64] == ref["iters"]).all()
