@@ -364,9 +364,19 @@ void user_host_eval(const double *s, const double *u, double *out, double *jac) 
 
 
 def cache_dir():
-    d = os.environ.get("MPCQP_CACHE_DIR") or os.path.join(_HERE, "_gen")
-    os.makedirs(d, exist_ok=True)
-    return d
+    """MPCQP_CACHE_DIR, else <package>/_gen, else a per-user directory under the system temp dir (read-only installs)"""
+    import tempfile
+    for d in (os.environ.get("MPCQP_CACHE_DIR"), os.path.join(_HERE, "_gen"),
+              os.path.join(tempfile.gettempdir(), "mpcqp_gen_%d" % os.getuid())):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            pass
+    raise RuntimeError("no writable directory for generated dynamics libraries (set MPCQP_CACHE_DIR)")
 
 
 def _build(src_text, suffix, cmd_prefix):
