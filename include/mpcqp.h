@@ -165,7 +165,9 @@ int mpcqp_debug_blockops(const double *A, const double *B, const double *C, cons
  * and its outputs are written straight into the device arrays mpcqp_update borrows (MPCQP_MEM_DEVICE), in the CSC value
  * order of mpcqp_stage_pattern -- so an SQP iteration never leaves the GPU.  Jacobians of F come from forward-mode dual
  * numbers inside the kernel (one thread per instance and QP column), not from finite differences.
- * np = nx (p is the reference state), n = np + horizon * (nx + nu), m = n + (horizon - 1) * nx. */
+ * np = nx (p is the reference state), n = np + horizon * (nx + nu), m = n + (horizon - 1) * nx + horizon * nh, where nh is the
+ * number of rows of an optional per-frame path constraint lo <= h(s_k, u_k) <= hi (generated libraries only; rows [p; x; g; h],
+ * their bounds travel in lbg / ubg behind the dynamics rows). */
 #define MPCQP_MODEL_DOUBLE_INTEGRATOR 0   /* nx 2, nu 1, exact discrete map; no parameters                       */
 #define MPCQP_MODEL_QUADROTOR 1           /* nx 12, nu 4, RK4; par = {mass, grav, arm, kappa, Jx, Jy, Jz}        */
 #define MPCQP_MODEL_CARTPOLE 2            /* nx 4, nu 1, RK4; par = {m_cart, m_pole, length, grav}               */

@@ -275,20 +275,32 @@ def _array_function(tape, func, args, kwargs):
     raise TypeError("NumPy function %s cannot be traced" % func.__name__)
 
 
-def trace(F, nx, nu):
-    """Run F once on tracers.  F(s, u) -> s_next with s [..., nx], u [..., nu] (the contract of models.StageOCP.F)."""
+def _trace_fn(fn, nx, nu, n_out, what):
     tape = Tape(nx + nu)
     s = TV(tape, [TS(tape, i) for i in range(nx)])
     u = TV(tape, [TS(tape, nx + i) for i in range(nu)])
-    out = F(s, u)
+    out = fn(s, u)
     if isinstance(out, TS):
         out = TV(tape, [out])
     if isinstance(out, (list, tuple)):
         out = TV(tape, [TS._lift(tape, v) for v in out])
-    if not isinstance(out, TV) or len(out) != nx:
-        raise ValueError("F must return the next state, %d components" % nx)
+    if not isinstance(out, TV) or len(out) != n_out:
+        raise ValueError("%s, %d components" % (what, n_out))
     tape.outputs = [TS._lift(tape, v).idx for v in out.items]
     tape.nx, tape.nu = nx, nu
+    return tape
+
+
+def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None):
+    """Run F (and the optional per-stage path constraint hfun) once on tracers.  F(s, u) -> s_next with s [..., nx],
+    u [..., nu] (the contract of models.StageOCP.F); hfun(s, u) -> [..., nh] with bounds h_lo <= hfun <= h_hi."""
+    tape = _trace_fn(F, nx, nu, nx, "F must return the next state")
+    tape.nh = int(nh) if hfun is not None else 0
+    tape.path = None
+    if tape.nh:
+        tape.path = _trace_fn(hfun, nx, nu, tape.nh, "hfun must return the path-constraint values")
+        tape.h_lo = [float(v) for v in np.broadcast_to(np.asarray(h_lo, float), (tape.nh,))]
+        tape.h_hi = [float(v) for v in np.broadcast_to(np.asarray(h_hi, float), (tape.nh,))]
     return tape
 
 
@@ -299,9 +311,8 @@ def _lit(v):
     return repr(float(v)) if "e" in repr(float(v)) or "." in repr(float(v)) else repr(float(v)) + ".0"
 
 
-def emit_functor(tape, name="SmUser"):
-    """C++ source of the functor (same shape as the zoo's functors in csrc/stage_models.hpp)"""
-    nx, nu = tape.nx, tape.nu
+def _emit_body(tape):
+    nx = tape.nx
     live = tape.live_nodes()
     ref = {}
     lines = []
@@ -320,9 +331,24 @@ def emit_functor(tape, name="SmUser"):
     for r, o in enumerate(tape.outputs):
         nd = tape.nodes[o]
         lines.append("    out[%d] = %s;" % (r, "T{} + %s" % ref[o] if nd[0] == "const" else ref[o]))
-    body = "\n".join(lines)
-    return ("struct %s {\n  static constexpr int nx = %d, nu = %d;\n"
-            "  template <class T> SM_HD static void F(const double *, double, const T *s, const T *u, T *out) {\n%s\n  }\n};\n" % (name, nx, nu, body))
+    return "\n".join(lines)
+
+
+def _blit(v):
+    return "INFINITY" if v == float("inf") else "-INFINITY" if v == float("-inf") else _lit(v)
+
+
+def emit_functor(tape, name="SmUser"):
+    """C++ source of the functor (same shape as the zoo's functors in csrc/stage_models.hpp)"""
+    nh = getattr(tape, "nh", 0)
+    hbody = _emit_body(tape.path) if nh else ""
+    src = ("struct %s {\n  static constexpr int nx = %d, nu = %d, nh = %d;\n"
+           "  template <class T> SM_HD static void F(const double *, double, const T *s, const T *u, T *out) {\n%s\n  }\n"
+           "  template <class T> SM_HD static void H(const T *s, const T *u, T *out) {\n%s\n  }\n};\n" % (name, tape.nx, tape.nu, nh, _emit_body(tape), hbody))
+    lo = ", ".join(_blit(v) for v in tape.h_lo) if nh else "0.0"
+    hi = ", ".join(_blit(v) for v in tape.h_hi) if nh else "0.0"
+    src += "static const double %s_h_lo[] = {%s};\nstatic const double %s_h_hi[] = {%s};\n" % (name, lo, name, hi)
+    return src
 
 
 _DEVICE_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- do not edit
@@ -332,6 +358,8 @@ _DEVICE_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- do n
 extern "C" {
 int mpcqp_user_abi() { return STAGE_ABI_VERSION; }
 void mpcqp_user_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
+int mpcqp_user_nh() { return SmUser::nh; }
+void mpcqp_user_path_bounds(double *lo, double *hi) { for (int i = 0; i < SmUser::nh; i++) { lo[i] = SmUser_h_lo[i]; hi[i] = SmUser_h_hi[i]; } }
 int mpcqp_user_eval(const StageDev *sd, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
                     const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, void *stream) {
   return (int)stage_launch_eval<SmUser>(*sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, (hipStream_t)stream);
@@ -343,6 +371,7 @@ int mpcqp_user_merit(const StageDev *sd, int batch, const double *p, const doubl
 '''
 
 _HOST_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- host build of the same functor, for checks without a GPU
+#include <cmath>
 #include "stage_models.hpp"
 
 %(functor)s
@@ -357,6 +386,18 @@ void user_host_eval(const double *s, const double *u, double *out, double *jac) 
     for (int i = 0; i < nu; i++) ud[i] = {u[i], nx + i == c ? 1.0 : 0.0};
     SmUser::F<Dual>(nullptr, 0.0, sd, ud, od);
     for (int r = 0; r < nx; r++) { jac[r * f + c] = od[r].d; out[r] = od[r].v; }
+  }
+}
+int user_host_nh() { return SmUser::nh; }
+// out [nh], jac [nh * (nx + nu)] row-major
+void user_host_path(const double *s, const double *u, double *out, double *jac) {
+  constexpr int nx = SmUser::nx, nu = SmUser::nu, f = nx + nu, nh = SmUser::nh;
+  for (int c = 0; c < f; c++) {
+    Dual sd[nx], ud[nu], od[nh > 0 ? nh : 1];
+    for (int i = 0; i < nx; i++) sd[i] = {s[i], i == c ? 1.0 : 0.0};
+    for (int i = 0; i < nu; i++) ud[i] = {u[i], nx + i == c ? 1.0 : 0.0};
+    SmUser::H<Dual>(sd, ud, od);
+    for (int r = 0; r < nh; r++) { jac[r * f + c] = od[r].d; out[r] = od[r].v; }
   }
 }
 }

@@ -83,18 +83,19 @@ int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d) {
   return MPCQP_OK;
 }
 
-static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, mpcqp_stage *s) {
+static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh, const double *h_lo, const double *h_hi, mpcqp_stage *s) {
   int dev = 0;
   if (int rc = mpcqp_pick_device(d->device, &dev)) return rc;
   s->desc = *d; s->device = dev;
   StageDev &sd = s->sd;
   sd.model = d->model; sd.N = d->horizon; sd.dt = d->dt; sd.nx = nx; sd.nu = nu;
   sd.f = sd.nx + sd.nu; sd.np = sd.nx; sd.nvar = sd.N * sd.f; sd.n = sd.np + sd.nvar;
-  sd.ng = (sd.N - 1) * sd.nx; sd.m = sd.n + sd.ng;
+  sd.nh = nh; sd.ngd = (sd.N - 1) * sd.nx; sd.ng = sd.ngd + sd.N * nh; sd.m = sd.n + sd.ng;
+  for (int i = 0; i < SM_MAXNH; i++) { sd.h_lo[i] = (h_lo && i < nh) ? h_lo[i] : -INFINITY; sd.h_hi[i] = (h_hi && i < nh) ? h_hi[i] : INFINITY; }
   for (int i = 0; i < SM_MAXNX; i++) sd.Q[i] = d->Q[i];
   for (int i = 0; i < SM_MAXNU; i++) sd.R[i] = d->R[i];
   for (int i = 0; i < SM_NPAR; i++) sd.par[i] = d->par[i];
-  sm_build_pattern(sd.nx, sd.nu, sd.N, s->Pp, s->Pi, s->Ap, s->Ai);
+  sm_build_pattern(sd.nx, sd.nu, sd.N, sd.nh, s->Pp, s->Pi, s->Ap, s->Ai);
   sd.nnzP = (int)s->Pi.size(); sd.nnzA = (int)s->Ai.size();
   if (hipSetDevice(dev) != hipSuccess) return mpcqp_set_error(MPCQP_ERR_HIP, "hipSetDevice failed");
   const size_t bytes = (size_t)(sd.n + 1) * sizeof(int);
@@ -116,7 +117,7 @@ int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out) {
   int nx, nu;
   sm_model_dims(d->model, &nx, &nu);
   mpcqp_stage *s = new mpcqp_stage();
-  if (int rc = stage_create_common(d, nx, nu, s)) { mpcqp_stage_destroy(s); return rc; }
+  if (int rc = stage_create_common(d, nx, nu, 0, nullptr, nullptr, s)) { mpcqp_stage_destroy(s); return rc; }
   *out = s;
   return MPCQP_OK;
 }
@@ -134,13 +135,20 @@ int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path,
   auto me = (user_merit_fn)dlsym(lib, "mpcqp_user_merit");
   if (!abi || !dims || !ev || !me) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_ARG, "the library does not export mpcqp_user_abi/dims/eval/merit"); }
   if (abi() != STAGE_ABI_VERSION) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_ARG, "the library was generated for another version of the stage kernels; regenerate it"); }
-  int nx = 0, nu = 0;
+  int nx = 0, nu = 0, nh = 0;
   dims(&nx, &nu);
-  if (nx <= 0 || nx > SM_MAXNX || nu <= 0 || nu > SM_MAXNU) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_LIMIT, "nx must be in 1..16 and nu in 1..8"); }
+  auto nhf = (int (*)())dlsym(lib, "mpcqp_user_nh");
+  auto hb = (void (*)(double *, double *))dlsym(lib, "mpcqp_user_path_bounds");
+  if (nhf) nh = nhf();
+  if (nx <= 0 || nx > SM_MAXNX || nu <= 0 || nu > SM_MAXNU || nh < 0 || nh > SM_MAXNH || (nh > 0 && !hb)) {
+    dlclose(lib); return mpcqp_set_error(MPCQP_ERR_LIMIT, "nx must be in 1..16, nu in 1..8 and the path constraint in 0..16 rows");
+  }
+  double h_lo[SM_MAXNH], h_hi[SM_MAXNH];
+  if (nh > 0) hb(h_lo, h_hi);
   mpcqp_stage *s = new mpcqp_stage();
   s->user_lib = lib; s->user_eval = ev; s->user_merit = me;
   mpcqp_stage_desc dd = *d; dd.model = MPCQP_MODEL_USER;
-  if (int rc = stage_create_common(&dd, nx, nu, s)) { mpcqp_stage_destroy(s); return rc; }
+  if (int rc = stage_create_common(&dd, nx, nu, nh, h_lo, h_hi, s)) { mpcqp_stage_destroy(s); return rc; }
   *out = s;
   return MPCQP_OK;
 }

@@ -7,10 +7,12 @@
 #include <hip/hip_runtime.h>
 #include "stage_models.hpp"
 
-#define STAGE_ABI_VERSION 1
+#define STAGE_ABI_VERSION 2
 
 struct StageDev {
-  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;
+  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows
+  int nh, ngd;
+  double h_lo[SM_MAXNH], h_hi[SM_MAXNH];   // path-constraint bounds, for the merit kernel's violation measure
   double dt;
   double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
   const int *Pp, *Ap;   // device copies of the column pointers
@@ -57,15 +59,17 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   int a = 0;
   Ac[a++] = 1.0;
   if (k >= 1 && c < nx) Ac[a++] = 1.0;
+  Dual s[nx], uu[nu];
+#pragma unroll
+  for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
+#pragma unroll
+  for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
   if (k < N - 1) {
-    Dual s[nx], uu[nu], out[nx];
-#pragma unroll
-    for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
-#pragma unroll
-    for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
+    Dual out[nx];
     M::template F<Dual>(sd.par, sd.dt, s, uu, out);
 #pragma unroll
     for (int r = 0; r < nx; r++) Ac[a + r] = -out[r].d;
+    a += nx;
     if (c < nx) {
       double Fc = 0.0;
 #pragma unroll
@@ -73,6 +77,21 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
       const double g = fr[f + c] - Fc;
       const int row = n + k * nx + c; const long gi = (long)b * sd.ng + k * nx + c;
       lb[row] = lbg[gi] - g; ub[row] = ubg[gi] - g;
+    }
+  }
+  if constexpr (M::nh > 0) {
+    // path constraint rows of this frame: column c of +dh/d[s; u]; lane c < nh also owns the shifted bounds of row h_k[c]
+    constexpr int nh = M::nh;
+    Dual hv[nh];
+    M::template H<Dual>(s, uu, hv);
+#pragma unroll
+    for (int r = 0; r < nh; r++) Ac[a + r] = hv[r].d;
+    for (int r0 = c; r0 < nh; r0 += f) {      // nh may exceed the frame size: lane c takes rows c, c + f, ...
+      double hc = 0.0;
+#pragma unroll
+      for (int r = 0; r < nh; r++) hc = r == r0 ? hv[r].v : hc;
+      const int row = n + sd.ngd + k * nh + r0; const long gi = (long)b * sd.ng + sd.ngd + k * nh + r0;
+      lb[row] = lbg[gi] - hc; ub[row] = ubg[gi] - hc;
     }
   }
 }
@@ -98,6 +117,12 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
       M::template F<double>(sd.par, sd.dt, s, uu, out);
 #pragma unroll
       for (int i = 0; i < nx; i++) gmax = fmax(gmax, fabs(fr[f + i] - out[i]));
+    }
+    if constexpr (M::nh > 0) {
+      double hv[M::nh];
+      M::template H<double>(s, uu, hv);
+#pragma unroll
+      for (int i = 0; i < M::nh; i++) gmax = fmax(gmax, fmax(sd.h_lo[i] - hv[i], hv[i] - sd.h_hi[i]));
     }
   }
   for (int o = 32; o >= 1; o >>= 1) { cost += __shfl_xor(cost, o, 64); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }

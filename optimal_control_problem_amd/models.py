@@ -144,6 +144,13 @@ class StageOCP:
     (addEquationConstraint, reference src/OptimalControlProblem.cpp:448-470)."""
 
     nx = 0; nu = 0; name = "ocp"
+    # optional per-stage path constraint lo <= h(s_k, u_k) <= hi, nh rows per frame (addInequalityConstraint, reference
+    # src/OptimalControlProblem.cpp:448-470); rows are stacked behind the dynamics rows: c = [p; x; g; h]
+    nh = 0; h_lo = None; h_hi = None
+
+    def hfun(self, s, u):
+        """[..., nh] path-constraint values; must accept complex input (override together with nh, h_lo, h_hi)"""
+        raise NotImplementedError
 
     def __init__(self, N, dt, Q, R):
         self.N, self.dt = int(N), float(dt)
@@ -152,7 +159,8 @@ class StageOCP:
         self.np = self.nx
         self.nvar = self.N * self.f
         self.n = self.np + self.nvar
-        self.ng = (self.N - 1) * self.nx
+        self.ngd = (self.N - 1) * self.nx                 # dynamics rows
+        self.ng = self.ngd + self.N * self.nh             # all general rows: dynamics, then nh path rows per frame
         self.m = self.n + self.ng
         self._build_pattern()
 
@@ -182,6 +190,8 @@ class StageOCP:
         self._A_id = np.zeros(n, np.int64)
         self._A_next = np.zeros((N, nx), np.int64)          # slot of +1 in row g_{k-1}[i], col s_k[i] (k>=1)
         self._A_blk = np.zeros((N - 1, nx, f), np.int64)    # slot of -dF[r, c] for stage k
+        nh = self.nh
+        self._A_h = np.zeros((N, nh, f), np.int64)          # slot of +dh[r, c] for frame k
         for j in range(npp):
             self._A_id[j] = len(Ai); Ai.append(j); Ap.append(len(Ai))
         for k in range(N):
@@ -193,6 +203,8 @@ class StageOCP:
                 if k < N - 1:
                     for r in range(nx):
                         self._A_blk[k, r, c] = len(Ai); Ai.append(n + k * nx + r)
+                for r in range(nh):
+                    self._A_h[k, r, c] = len(Ai); Ai.append(n + (N - 1) * nx + k * nh + r)
                 Ap.append(len(Ai))
         self.Ap = np.asarray(Ap, np.int32); self.Ai = np.asarray(Ai, np.int32)
 
@@ -232,9 +244,28 @@ class StageOCP:
         e = s - p[:, None, :]
         return np.einsum("bki,i->b", e * e, self.Q) + np.einsum("bki,i->b", u * u, self.R)
 
+    def dh(self, s, u):
+        """[..., nh, f] Jacobian of hfun wrt [s; u] by complex-step differentiation"""
+        eps = 1e-30
+        out = np.empty(s.shape[:-1] + (self.nh, self.f))
+        sc = s.astype(complex); uc = u.astype(complex)
+        for c in range(self.f):
+            if c < self.nx:
+                sp = sc.copy(); sp[..., c] += 1j * eps
+                out[..., :, c] = np.asarray(self.hfun(sp, uc)).imag / eps
+            else:
+                up = uc.copy(); up[..., c - self.nx] += 1j * eps
+                out[..., :, c] = np.asarray(self.hfun(sc, up)).imag / eps
+        return out
+
     def constraints(self, x):
+        """dynamics defects only (the equality rows)"""
         s, u = self.frames(x)
         return (s[:, 1:, :] - self.F(s[:, :-1, :], u[:, :-1, :])).reshape(x.shape[0], -1)
+
+    def path_values(self, x):
+        s, u = self.frames(x)
+        return np.asarray(self.hfun(s, u)).reshape(x.shape[0], -1)
 
     def local_system(self, p, x, lbx, ubx, lbg, ubg):
         B = x.shape[0]; N, nx, nu, f, npp, n = self.N, self.nx, self.nu, self.f, self.np, self.n
@@ -256,6 +287,9 @@ class StageOCP:
         A[:, self._A_next[1:].ravel()] = 1.0
         A[:, self._A_blk.ravel()] = -J.reshape(B, -1)
         g = (s[:, 1:, :] - self.F(s[:, :-1, :], u[:, :-1, :])).reshape(B, -1)
+        if self.nh:
+            A[:, self._A_h.ravel()] = self.dh(s, u).reshape(B, -1)
+            g = np.concatenate([g, np.asarray(self.hfun(s, u)).reshape(B, -1)], axis=1)
         c = np.concatenate([p, x, g], axis=1)
         l = np.concatenate([p, lbx, lbg], axis=1) - c
         uu = np.concatenate([p, ubx, ubg], axis=1) - c
@@ -272,6 +306,8 @@ class StageOCP:
         lbx = np.tile(lo, (B, self.N)); ubx = np.tile(hi, (B, self.N))
         lbx[:, :self.f] = frame0; ubx[:, :self.f] = frame0
         lbg = np.zeros((B, self.ng)); ubg = np.zeros((B, self.ng))
+        if self.nh:
+            lbg[:, self.ngd:] = np.tile(np.asarray(self.h_lo, float), self.N); ubg[:, self.ngd:] = np.tile(np.asarray(self.h_hi, float), self.N)
         return lbx, ubx, lbg, ubg
 
 

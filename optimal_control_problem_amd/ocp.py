@@ -53,6 +53,14 @@ class Dynamics(Expr):
         self.size = state.size
 
 
+class Path(Expr):
+    """h(state, input) of one frame: a per-stage path-constraint expression given as a NumPy callable on [..., nx], [..., nu]
+    returning [..., size]; used with addInequalityConstraint(name, lower, Path(...), upper)"""
+
+    def __init__(self, h, state, inp, size):
+        self.h, self.state, self.inp, self.size = h, state, inp, int(size)
+
+
 # ---------------------------------------------------------------------------------------------------- OCPConfig
 def _bound_value(v):
     """'.inf' / '-.inf' strings as the reference handles them (OCPConfig.cpp:152-159); PyYAML already yields floats"""
@@ -140,12 +148,16 @@ class OCPConfig:
 class _FacadeStageOCP(models.StageOCP):
     name = "facade_ocp"
 
-    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi):
+    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi, h=None, nh=0, h_lo=None, h_hi=None):
         self.nx, self.nu, self._F, self._lo, self._hi = nx, nu, F, lo, hi
+        self._h, self.nh, self.h_lo, self.h_hi = h, int(nh), h_lo, h_hi
         super().__init__(N, dt, Q, R)
 
     def F(self, s, u):
         return self._F(s, u)
+
+    def hfun(self, s, u):
+        return self._h(s, u)
 
     def frame_bounds(self):
         return self._lo, self._hi
@@ -257,9 +269,12 @@ class OptimalControlProblem:
     def _compile_stage_model(self):
         cfg = self.OCPConfigPtr_
         N, f = cfg.getHorizon(), cfg.getFrameSize()
-        dyn = [c for c in self.constraints_ if isinstance(c, Diff) and isinstance(c.b, Dynamics)]
-        if len(dyn) != len(self.constraints_) or len(dyn) != N - 1:
-            raise NotImplementedError("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames only")
+        dyn_idx = [i for i, c in enumerate(self.constraints_) if isinstance(c, Diff) and isinstance(c.b, Dynamics)]
+        path_idx = [i for i, c in enumerate(self.constraints_) if isinstance(c, Path)]
+        dyn = [self.constraints_[i] for i in dyn_idx]; path = [self.constraints_[i] for i in path_idx]
+        if len(dyn) + len(path) != len(self.constraints_) or len(dyn) != N - 1 or len(path) not in (0, N):
+            raise NotImplementedError("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames and one "
+                                      "per-frame path constraint Path(h, state_k, input_k) on every frame")
         s0, u0, F = dyn[0].b.state, dyn[0].b.inp, dyn[0].b.F
         nx, nu = s0.size, u0.size
         if s0.offset != 0 or u0.offset != nx or nx + nu != f:
@@ -286,7 +301,18 @@ class OptimalControlProblem:
             raise NotImplementedError("tracking and input costs must be added for every step")
         if self.reference_ is None or self.reference_.size != nx:
             raise NotImplementedError("reference must have the state's dimension")
-        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0])
+        h = None; nh = 0; h_lo = h_hi = None
+        if path:
+            path.sort(key=lambda c: c.state.step); path_idx.sort(key=lambda i: self.constraints_[i].state.step)
+            h, nh = path[0].h, path[0].size
+            h_lo, h_hi = self.constraintLowerBounds_[path_idx[0]], self.constraintUpperBounds_[path_idx[0]]
+            for k, (c, i) in enumerate(zip(path, path_idx)):
+                if not (c.h is h and c.size == nh and c.state.step == k and c.inp.step == k and c.state.name == s0.name and c.inp.name == u0.name
+                        and np.array_equal(self.constraintLowerBounds_[i], h_lo) and np.array_equal(self.constraintUpperBounds_[i], h_hi)):
+                    raise NotImplementedError("the path constraint must be the same function and bounds on every frame")
+        # rows of the compiled model: dynamics rows in frame order, then the path rows in frame order
+        self._row_order = [i for _, i in sorted((self.constraints_[i].a.step, i) for i in dyn_idx)] + path_idx
+        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi)
 
     # -- computeOptimalTrajectory (:78-222), CUDA_SQP arm
     def computeOptimalTrajectory(self, frame, reference):
@@ -301,8 +327,9 @@ class OptimalControlProblem:
         ubx = np.tile(np.concatenate(cfg.getUpperBounds()), (self.batch, 1))
         fs = cfg.getFrameSize()
         lbx[:, :fs] = frame; ubx[:, :fs] = frame                                       # :95-96 the whole first frame is pinned
-        lbg = np.tile(np.concatenate(self.constraintLowerBounds_), (self.batch, 1))
-        ubg = np.tile(np.concatenate(self.constraintUpperBounds_), (self.batch, 1))
+        order = getattr(self, "_row_order", range(len(self.constraintLowerBounds_)))
+        lbg = np.tile(np.concatenate([self.constraintLowerBounds_[i] for i in order]), (self.batch, 1))
+        ubg = np.tile(np.concatenate([self.constraintUpperBounds_[i] for i in order]), (self.batch, 1))
         x0 = np.zeros((self.batch, cfg.getVariables())) if self.firstTime_ or self.optimalTrajectory_ is None else self.optimalTrajectory_
         arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, x0=x0, p=reference)
         if not self.solverInputCheck(arg):

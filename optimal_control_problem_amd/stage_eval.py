@@ -65,7 +65,9 @@ class StageEvaluator:
         self.library = None
         if model is not None:
             zoo = model.name in MODEL_IDS and type(model).__name__ in ("DoubleIntegrator", "Quadrotor", "CartPole")
-            use_codegen = (not zoo) if codegen is None else bool(codegen)
+            use_codegen = (not zoo or model.nh > 0) if codegen is None else bool(codegen)
+            if model.nh > 0 and not use_codegen:
+                raise ValueError("a path constraint needs the generated evaluator (codegen=True)")
             _lib.check(L.mpcqp_stage_default(MODEL_IDS.get(model.name, 0) if zoo else 0, int(model.N), C.byref(d)))
             d.dt = float(model.dt)
             if len(model.Q) > 16 or len(model.R) > 8:
@@ -75,7 +77,7 @@ class StageEvaluator:
             for i in range(8): d.par[i] = 0.0
             if use_codegen:
                 from . import codegen as cg
-                self.tape = cg.trace(model.F, model.nx, model.nu)
+                self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi)
                 self.library = cg.build_device_library(self.tape)
             else:
                 for i, v in enumerate(model_params(model)): d.par[i] = float(v)

@@ -96,3 +96,44 @@ def test_device_library_cross_compiles_and_exports(built):
     syms = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
     for name in ("mpcqp_user_abi", "mpcqp_user_dims", "mpcqp_user_eval", "mpcqp_user_merit"):
         assert name in syms
+
+
+class CartPoleWall(models.CartPole):
+    """cart-pole with a per-stage path constraint: the pole tip stays left of a wall, and a coupled state/input limit"""
+    name = "cartpole_wall"; nh = 2; h_lo = [-np.inf, -3.0]; h_hi = [1.5, 3.0]
+
+    def hfun(self, s, u):
+        return np.stack([s[..., 0] + self.length * np.sin(s[..., 1]), s[..., 2] + 0.1 * u[..., 0]], axis=-1)
+
+
+def test_path_constraint_host_formulation_and_generated_functor(built):
+    """rows [p; x; g; h]: A's h rows are +dh/dw (checked against central differences), l/u are the bounds shifted by h(x);
+    the traced + generated H functor (g++ build) reproduces hfun and its complex-step Jacobian"""
+    mdl = CartPoleWall(8, 0.02)
+    assert (mdl.ngd, mdl.ng, mdl.m) == (7 * 4, 7 * 4 + 8 * 2, mdl.n + 7 * 4 + 8 * 2)
+    rng = np.random.default_rng(0); B = 2
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = rng.normal(0, 0.1, (B, 4))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    _, A = ls.dense(0)
+    def rows(xv):
+        return np.concatenate([mdl.constraints(xv[None])[0], mdl.path_values(xv[None])[0]])
+    J = np.zeros((mdl.ng, mdl.nvar))
+    for j in range(mdl.nvar):
+        d = np.zeros(mdl.nvar); d[j] = 1e-6
+        J[:, j] = (rows(x[0] + d) - rows(x[0] - d)) / 2e-6
+    assert np.abs(A[mdl.n:, mdl.np:] - J).max() < 1e-8
+    hv = mdl.path_values(x)
+    assert np.array_equal(ls.u[:, mdl.n + mdl.ngd:], np.tile(mdl.h_hi, mdl.N) - hv) and np.isneginf(ls.l[:, mdl.n + mdl.ngd]).all()
+    for j in range(ls.n):
+        assert (np.diff(ls.Ai[ls.Ap[j]:ls.Ap[j + 1]]) > 0).all()
+    tape = codegen.trace(mdl.F, mdl.nx, mdl.nu, mdl.hfun, mdl.nh, mdl.h_lo, mdl.h_hi)
+    L = C.CDLL(codegen.build_host_library(tape)); L.user_host_path.argtypes = [C.c_void_p] * 4
+    assert L.user_host_nh() == 2
+    s, u = x[0, :4].copy(), x[0, 4:5].copy()
+    out = np.zeros(2); jac = np.zeros((2, 5))
+    L.user_host_path(s.ctypes.data, u.ctypes.data, out.ctypes.data, jac.ctypes.data)
+    assert np.abs(out - mdl.hfun(s, u)).max() < 1e-15 and np.abs(jac - mdl.dh(s[None], u[None])[0]).max() < 1e-13
+    src = codegen.emit_functor(tape)
+    assert "nh = 2" in src and "-INFINITY" in src
+    assert os.path.exists(codegen.build_device_library(tape))

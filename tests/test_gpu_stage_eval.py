@@ -204,3 +204,84 @@ def test_device_sqp_constant_matrices_matches_oracle_kept_workspace(built):
         s0 = arg["lbx"][:, :mdl.nx] + rng.normal(0, 0.05, (B, mdl.nx))
         arg["lbx"][:, :mdl.nx] = s0; arg["ubx"][:, :mdl.nx] = s0
     dev.close()
+
+
+def test_path_constraints_on_device(built):
+    """per-stage path constraint lo <= h(s_k, u_k) <= hi through the generated evaluator: QP data equal to the host formulation,
+    the QP honours the linearised constraint, and the device SQP loop equals the host loop"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    from tests.test_codegen import CartPoleWall
+    B, N = 20, 12
+    mdl = CartPoleWall(N, 0.02)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = np.zeros((B, 4))
+    frame0 = x[:, :mdl.f].copy(); frame0[:, 0] = rng.uniform(-0.5, 0.5, B)
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    ref = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    ev = StageEvaluator(mdl)
+    assert ev.library is not None and (ev.m, ev.ng) == (mdl.m, mdl.ng) and (ev.Ai == mdl.Ai).all() and (ev.Ap == mdl.Ap).all()
+    out = ev.eval(_dev(p), _dev(x), _dev(lbx), _dev(ubx), _dev(lbg), _dev(ubg))
+    for k, r in (("P", ref.P), ("q", ref.q), ("A", ref.A), ("l", ref.l), ("u", ref.u)):
+        assert _close(out[k].cpu().numpy(), r, 1e-12), k
+    f, g = ev.merit(_dev(p), _dev(x))
+    hv = mdl.path_values(x).reshape(B, N, 2)
+    viol = np.maximum(np.maximum(np.asarray(mdl.h_lo) - hv, hv - np.asarray(mdl.h_hi)).max(axis=(1, 2)), np.abs(mdl.constraints(x)).max(axis=1))
+    assert _close(g.cpu().numpy(), viol, 1e-11)
+    qp = BatchQP(ev.n, ev.m, B, ev.Pp, ev.Pi, ev.Ap, ev.Ai)
+    qp.update(out["P"], out["q"], out["A"], out["l"], out["u"]); qp.solve(); got = qp.get(); qp.close()
+    assert (got["status"] == 1).all()
+    z = got["z"][:, mdl.n + mdl.ngd:]                       # A dx on the path rows stays inside the shifted bounds (ADMM tolerance)
+    assert (z <= ref.u[:, mdl.n + mdl.ngd:] + 1e-2).all()
+    ev.close()
+    arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, p=p)
+    host = SQPOptimizationSolver(mdl, {"max_iter": 5, "alpha": 0.6}, batch=B); dev = DeviceSQPOptimizationSolver(mdl, {"max_iter": 5, "alpha": 0.6}, batch=B)
+    host.setInitialGuess(x); dev.setInitialGuess(x)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * (1 + np.abs(rh["x"]).max())
+    assert (mdl.path_values(rd["x"]).reshape(B, N, 2)[:, 1:, 0] <= 1.5 + 5e-2).all()
+    host.qpSolver_.close(); dev.close()
+
+
+def test_facade_path_constraint(built):
+    """OptimalControlProblem.addInequalityConstraint with a per-frame Path(...) expression, device-resident (gen_code: true)"""
+    import yaml
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem, Path
+    from tests.test_codegen import pendulum_on_cart_with_drag
+    text = """
+      discretization_settings: {dt: 0.01, horizon: 10}
+      solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 0.8, step_num: 4}}
+      OCP_variables:
+        - {name: state, size: 3, lower_bound: [-.inf, -.inf, -3.0], upper_bound: [.inf, .inf, 3.0]}
+        - {name: input, size: 1, lower_bound: [-5.0], upper_bound: [5.0]}
+    """
+    def power(s, u):                                       # |velocity * force| bounded: a coupled state-input constraint
+        return np.stack([s[..., 2] * u[..., 0]], axis=-1)
+
+    class Pendulum(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_
+            ref = self.setReference(3)
+            for k in range(cfg.getHorizon()):
+                self.addVectorCost([5.0, 0.5, 0.2], cfg.getVariable(k, "state") - ref)
+                self.addVectorCost([0.05], cfg.getVariable(k, "input"))
+                # interleaved with the dynamics on purpose: the facade sorts the rows into [dynamics; path]
+                self.addInequalityConstraint("power", [-0.4], Path(power, cfg.getVariable(k, "state"), cfg.getVariable(k, "input"), 1), [0.4])
+                if k < cfg.getHorizon() - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"),
+                                               Dynamics(pendulum_on_cart_with_drag, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+
+    B = 8
+    rng = np.random.default_rng(9)
+    frame = np.concatenate([rng.normal(0, 0.4, (B, 3)), np.zeros((B, 1))], axis=1); ref = np.zeros((B, 3))
+    res = {}
+    for flag in ("false", "true"):
+        ocp = Pendulum(yaml.safe_load(text % flag), batch=B)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert (ocp.model_.nh, ocp.model_.ng) == (1, 9 * 3 + 10)
+        res[flag] = ocp.computeOptimalTrajectory(frame, ref)
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
+    X = res["true"].reshape(B, 10, 4)
+    assert (np.abs(X[:, 1:, 2] * X[:, 1:, 3]) <= 0.4 + 5e-2).all()
