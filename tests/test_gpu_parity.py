@@ -456,3 +456,27 @@ def test_dispatch_hint_changes_no_result(built):
     qp.close()
     ref = problems.oracle_solve(models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[:64], ls.q[:64], ls.A[:64], ls.l[:64], ls.u[:64]))
     assert (first["iters"][:64] == ref["iters"]).all()
+
+
+def test_two_handles_on_two_streams(built):
+    """distinct handles are independent (include/mpcqp.h): two batches solved concurrently on two HIP streams give the
+    results of solving them one after the other"""
+    import torch
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, a, _ = models.make_workload("quadrotor", 300, N=10)
+    _, b, _ = models.make_workload("cartpole", 500, N=30)
+    seq = []
+    for ls in (a, b):
+        qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai); qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); seq.append(qp.get()); qp.close()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    qa = BatchQP(a.n, a.m, a.batch, a.Pp, a.Pi, a.Ap, a.Ai); qb = BatchQP(b.n, b.m, b.batch, b.Pp, b.Pi, b.Ap, b.Ai)
+    da = [torch.as_tensor(v, device="cuda") for v in (a.P, a.q, a.A, a.l, a.u)]
+    db = [torch.as_tensor(v, device="cuda") for v in (b.P, b.q, b.A, b.l, b.u)]
+    torch.cuda.synchronize()
+    for _ in range(3):                                   # several rounds in flight on both streams
+        qa.update(*da); qa.solve(s1.cuda_stream)
+        qb.update(*db); qb.solve(s2.cuda_stream)
+    ga, gb = qa.get(), qb.get()
+    for got, ref in ((ga, seq[0]), (gb, seq[1])):
+        assert np.array_equal(got["x"], ref["x"]) and np.array_equal(got["iters"], ref["iters"]) and np.array_equal(got["status"], ref["status"])
+    qa.close(); qb.close()
