@@ -61,6 +61,13 @@ struct DevIO {
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
+// A value every lane holds identically (the result of a workgroup reduction, rho, the cost scale): moved to scalar registers,
+// so that state that lives across the whole ADMM loop does not occupy vector registers of the 128-VGPR kernel instances.
+__device__ __forceinline__ double uni(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -672,14 +679,18 @@ __device__ __forceinline__ double ell_batch(const double *__restrict__ &vp, cons
   vp += U * WAVE; ip += U * WAVE;
   return acc;
 }
-template <bool MAXABS>
+template <bool MAXABS, int UMAX = 16>
 __device__ __forceinline__ double ell_chunk(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
   const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
   const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
   double acc = 0.0;
   int rem = s1 - s0;
-  for (; rem >= 16; rem -= 16) acc = ell_batch<MAXABS, 16>(vp, ip, in, acc);
-  if (rem & 8) acc = ell_batch<MAXABS, 8>(vp, ip, in, acc);
+  if (UMAX >= 16) {
+    for (; rem >= 16; rem -= 16) acc = ell_batch<MAXABS, 16>(vp, ip, in, acc);
+    if (rem & 8) acc = ell_batch<MAXABS, 8>(vp, ip, in, acc);
+  } else {
+    for (; rem >= 8; rem -= 8) acc = ell_batch<MAXABS, 8>(vp, ip, in, acc);     // 16 loads in flight spill in the 128-VGPR instances
+  }
   if (rem & 4) acc = ell_batch<MAXABS, 4>(vp, ip, in, acc);
   if (rem & 2) acc = ell_batch<MAXABS, 2>(vp, ip, in, acc);
   if (rem & 1) acc = ell_batch<MAXABS, 1>(vp, ip, in, acc);
@@ -687,9 +698,9 @@ __device__ __forceinline__ double ell_chunk(const double *__restrict__ val, cons
 }
 // ELL sweeps for the multi-wave kernels: wave `wid` takes chunks wid, wid + NW, ... (A 16-deep clamped full unroll
 // and a 4-lanes-per-row split were both measured slower on MI355X: spills / more latency rounds; see DESIGN.md.)
-template <int NW, class F>
+template <int NW, int UMAX = 16, class F>
 __device__ __forceinline__ void ell_rows_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<false>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
+  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<false, UMAX>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
 }
 template <int NW, class F>
 __device__ __forceinline__ void ell_rowmax_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
@@ -1034,10 +1045,10 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
     }
   }
   block_combine<NW, 15, 1>(v, cx.RED, wid, lane);
-  in.prim_res = v[0]; in.nz = v[1]; in.nax = v[2]; in.prs = v[3]; in.nzs = v[4]; in.naxs = v[5];
-  in.dual_res = unscale ? cx.cinv * v[6] : v[6]; in.nq = v[7]; in.naty = v[8]; in.npx = v[9];
-  in.drs = v[10]; in.nqs = v[11]; in.natys = v[12]; in.npxs = v[13];
-  in.obj = cx.st->scaling ? cx.cinv * v[14] : v[14];
+  in.prim_res = uni(v[0]); in.nz = uni(v[1]); in.nax = uni(v[2]); in.prs = uni(v[3]); in.nzs = uni(v[4]); in.naxs = uni(v[5]);
+  in.dual_res = uni(unscale ? cx.cinv * v[6] : v[6]); in.nq = uni(v[7]); in.naty = uni(v[8]); in.npx = uni(v[9]);
+  in.drs = uni(v[10]); in.nqs = uni(v[11]); in.natys = uni(v[12]); in.npxs = uni(v[13]);
+  in.obj = uni(cx.st->scaling ? cx.cinv * v[14] : v[14]);
 }
 
 template <int NW>
@@ -1140,6 +1151,7 @@ template <int NW, int MINW, bool GB, bool REUSE>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
+  constexpr int EU = 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower)
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1193,7 +1205,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     }
     block_combine<NW, 1, 0>(chg, cx.RED, wid, lane);
     refactor = chg[0] != 0.0;
-    cx.c = c; cx.cinv = 1.0 / c;
+    c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
     if (!GB) {   // the factor blocks come back from the slab
       const double *src = ws + pl.o_Lf;
       for (long e = tid; e < (long)pl.nblk * BLK; e += NT) lds[e] = src[e];
@@ -1236,7 +1248,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       c *= ct;
       bsync<NW>();
     }
-    cx.c = c; cx.cinv = 1.0 / c;
+    c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
     TS(1);
     // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
     for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
@@ -1268,7 +1280,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     bsync<NW>();
   }
   // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
-  cx.rho = reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX);
+  cx.rho = uni(reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX));
   int status = MPCQP_UNSOLVED, iter_done = 0;
   Info in; memset(&in, 0, sizeof(in));
   TS(2);
@@ -1290,7 +1302,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
-      ell_rows_w<NW>(pl.At, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      ell_rows_w<NW, EU>(pl.At, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
       bsync<NW>();
       TS(4);
 #ifdef MPCQP_TIMING
@@ -1310,11 +1322,11 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.
         // l, u are fetched before the row sum is accumulated; rho_i and 1/rho_i are selected from the three values
         // the rho rule can produce (no per-row division).
-        const double rho_eq = Q_RHO_EQ * cx.rho, ri_min = 1.0 / Q_RHO_MIN, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / cx.rho;
+        const double rho_eq = uni(Q_RHO_EQ * cx.rho), ri_min = 1.0 / Q_RHO_MIN, ri_eq = uni(1.0 / rho_eq), ri_in = uni(1.0 / cx.rho);
         for (int c = wid; c < pl.A.nchunks; c += NW) {
           const int i = c * WAVE + lane;
           const double lo = lb[i], up = ub[i];
-          const double zt = ell_chunk<false>(valA, pl.A.idx, cx.R, pl.A.chunk_off[c], pl.A.chunk_off[c + 1], lane);
+          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, pl.A.chunk_off[c], pl.A.chunk_off[c + 1], lane);
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
@@ -1348,7 +1360,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         double rn = cx.rho * sqrt(pr / (dr + Q_DIV_TOL));
         rn = fmin(fmax(rn, Q_RHO_MIN), Q_RHO_MAX);
         if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
-          cx.rho = rn;
+          cx.rho = uni(rn);
           if (!factorize_res<NW>(cx)) { status = MPCQP_NON_CVX; break; }
         }
       }
