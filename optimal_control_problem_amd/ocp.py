@@ -236,6 +236,28 @@ class OptimalControlProblem:
         self.constraints_.append(expr); self.constraintNames_ += [constraintName] * expr.size
         self.constraintLowerBounds_.append(np.zeros(expr.size)); self.constraintUpperBounds_.append(np.zeros(expr.size))
 
+    def getCostFunction(self):
+        """the list of cost terms (the reference sums SX terms into totalCost_, OptimalControlProblem.cpp:491-497)"""
+        self.totalCost_ = list(self.costs_)
+        return self.totalCost_
+
+    def setSolverType(self, solverType):                                             # :499-505
+        name = solverType.name if hasattr(solverType, "name") else str(solverType)
+        if name not in self.SOLVER_TYPES:
+            raise ValueError("Unknown solver type: " + name)
+        self.solverType = name
+
+    def getSolverType(self):
+        return self.solverType
+
+    def genCode(self):
+        """generate + compile the local-system evaluation for the GPU (the reference's genCode writes C for the NLP solver and
+        shells out to gcc, OptimalControlProblem.cpp:263-287,602-640); returns the path of the shared library"""
+        from . import codegen
+        model = self.model_ if self.model_ is not None else self._compile_stage_model()
+        tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi)
+        return codegen.build_device_library(tape)
+
     def getConstraints(self):
         return self.constraints_
 

@@ -161,3 +161,38 @@ def test_admm_warm_start_across_sqp_iterations(built):
     assert np.abs(rc["f"] - rw["f"]).max() <= 2e-2 * (1 + np.abs(rc["f"]).max())
     assert np.abs(mdl.constraints(rw["x"])).max() <= 2 * np.abs(mdl.constraints(rc["x"])).max() + 1e-3
     cold.qpSolver_.close(); warm.qpSolver_.close()
+
+
+def test_ocp_module_snake_case_surface(built):
+    """the module the reference's (commented-out) pybind file defines -- ocp_module with SolverType and snake_case methods
+    (reference src/pybind/python_bindings.cpp:409-446) -- over the same facade"""
+    from optimal_control_problem_amd import ocp_module
+    from tests.support.oracle_backend import OracleCuCaQP
+
+    class DI(ocp_module.OptimalControlProblem):
+        def deploy_constraints_and_add_cost(self):
+            cfg = self.OCPConfigPtr_
+            h = cfg.getDt()
+            F = lambda s, u: np.stack([s[..., 0] + h * s[..., 1] + 0.5 * h * h * u[..., 0], s[..., 1] + h * u[..., 0]], axis=-1)
+            ref = self.set_reference(2)
+            for k in range(cfg.getHorizon()):
+                self.add_vector_cost([10.0, 1.0], cfg.getVariable(k, "state") - ref)
+                self.add_vector_cost([0.1], cfg.getVariable(k, "input"))
+            for k in range(cfg.getHorizon() - 1):
+                self.add_equation_constraint("dynamics", cfg.getVariable(k + 1, "state"),
+                                             ocp_module.Dynamics(F, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+
+    ocp = DI(_node(), batch=2, qp_solver=OracleCuCaQP(batch=2))
+    assert ocp.get_solver_type() is ocp_module.CUDA_SQP
+    ocp.set_solver_type(ocp_module.SolverType.IPOPT); assert ocp.get_solver_type() is ocp_module.IPOPT
+    ocp.set_solver_type(ocp_module.CUDA_SQP)
+    ocp.deploy_constraints_and_add_cost()
+    assert len(ocp.get_constraints()) == 19 and len(ocp.get_cost_function()) == 40 and len(ocp.get_constraint_lower_bounds()) == 19
+    ocp.gen_solver()
+    frame, ref, traj = _tick(ocp, 2)
+    assert traj.shape == (2, 60) and np.array_equal(ocp.get_optimal_trajectory(), traj)
+    lib = ocp.gen_code()                                    # traced dynamics -> gfx950 library (cross-compiles without a GPU)
+    import os
+    assert os.path.exists(lib) and lib.endswith(".so")
+    with pytest.raises(NotImplementedError):
+        ocp_module.OptimalControlProblem(_node()).deploy_constraints_and_add_cost()
