@@ -43,3 +43,32 @@ def random_qp(n, m, seed, density=0.3, infeasible=None):
     hm = np.ones((n, n), bool); am = np.ones((m, n), bool)
     Pp, Pi = models._csc_from_dense_mask(hm); Ap, Ai = models._csc_from_dense_mask(am)
     return models.LocalSystem(n, m, Pp, Pi, Ap, Ai, P.T[hm.T][None].copy(), q[None].copy(), A.T[am.T][None].copy(), l[None].copy(), u[None].copy())
+
+
+def sparse_batch(n, m, B, seed, dens):
+    """Batch of B convex QPs sharing a random SPARSE pattern (symmetric P mask with full diagonal, A mask with no empty row),
+    mixed equality / inequality / one-sided rows."""
+    rng = np.random.default_rng(seed)
+    hm = np.eye(n, dtype=bool) | (rng.random((n, n)) < dens)
+    hm = hm | hm.T
+    am = rng.random((m, n)) < dens
+    for i in range(m):
+        if not am[i].any():
+            am[i, rng.integers(n)] = True
+    Pp, Pi = models._csc_from_dense_mask(hm); Ap, Ai = models._csc_from_dense_mask(am)
+    Ps, As, qs, ls, us = [], [], [], [], []
+    for b in range(B):
+        Mx = rng.normal(size=(n, n)) * hm * (rng.random((n, n)) < 0.7)
+        L = np.tril(Mx); P = L @ L.T
+        P = P * hm + np.diag(np.abs(P).sum(axis=1) * (1 - hm).sum(axis=1) + 0.1)      # masked + diagonally dominant => PSD
+        P = 0.5 * (P + P.T)
+        A = rng.normal(size=(m, n)) * am
+        xf = rng.normal(size=n); ax = A @ xf
+        l = ax - rng.random(m); u = ax + rng.random(m)
+        kind = rng.integers(0, 4, size=m)
+        l[kind == 1] = -np.inf; u[kind == 2] = np.inf
+        eq = kind == 3; u[eq] = l[eq] = ax[eq]
+        Ps.append(P.T[hm.T]); As.append(A.T[am.T]); qs.append(rng.normal(size=n)); ls.append(l); us.append(u)
+    return models.LocalSystem(n, m, Pp, Pi, Ap, Ai, np.array(Ps), np.array(qs), np.array(As), np.array(ls), np.array(us))
+
+
