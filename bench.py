@@ -146,6 +146,7 @@ def main():
         value = total / elapsed
         abytes = algorithmic_bytes_per_solve(pinfo["nnzP_triu"], pinfo["nnzA"], ls.n, ls.m)
         achieved = abytes * batch / (kms * 1e-3) / 1e9
+        flops_iter = 4 * pinfo["L_blocks"] * 256 + 2 * (2 * pinfo["nnzA"]) + 2 * (2 * pinfo["nnzP_triu"] - ls.n) + 12 * (ls.n + ls.m)
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if any
         try:
             tbl = json.load(open(os.path.join(ROOT, "profiles", "traffic_table.json")))
@@ -168,7 +169,13 @@ def main():
                          "achieved_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9,
                          "frac_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel": "mpcqp_res_kernel" if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
-                         "algorithmic_bytes_per_solve": abytes},
+                         "algorithmic_bytes_per_solve": abytes,
+                         # flops of one ADMM iteration = two block-triangular solves + A x, A'y + P x + vector work
+                         "algorithmic_flops_per_admm_iter": flops_iter,
+                         "achieved_tflops_fp64": flops_iter * (iters_sum / world) / (kms * 1e-3) / 1e12,
+                         "fp64_vector_peak_tflops": FP64_VEC_PEAK_TFLOPS,
+                         "regime": ("factor blocks and A / A' values re-streamed from HBM every ADMM iteration (occupancy beats LDS residency at this size)"
+                                    if pinfo["variant"] >= 100 or pinfo["variant"] == 0 else "factor resident in LDS; A / A' values re-read from L2 / HBM every ADMM iteration")},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
                             "admm_iters_per_s": iters_sum / (kms_max * 1e-3),
                             "lds_bytes_per_qp": pinfo["lds_bytes"], "workspace_bytes_per_qp": pinfo["workspace_bytes_per_qp"],
