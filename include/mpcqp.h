@@ -114,6 +114,17 @@ int mpcqp_set_rho(mpcqp_handle *h, const double *rho0, int mem);
  * Asynchronous: returns after the launch; results are ordered on `stream`. */
 int mpcqp_solve(mpcqp_handle *h, void *stream);
 
+/* Fused host-buffer step for large batches: CuCaQP::setSystem + initSolver + solve + getSolution (CuCaQP.cpp:183-224,271-288) in
+ * one call, pipelined -- the batch is cut into `chunks` slices (0 = 6); all host-to-device copies queue on one internal stream
+ * in slice order, each slice's kernel and its device-to-host copies run on one of several compute streams as soon as its inputs
+ * have landed, so transfers overlap the kernels of earlier slices ("streams matrices via pinned hipMemcpyAsync").  Arrays are dense and instance-major (stride = width; strideP / strideA may be 0 for matrices shared by the
+ * batch); x [batch*n], y [batch*m], status, iters [batch] may be NULL.  The copies are asynchronous only from / to pinned host
+ * memory (hipHostMalloc, hipHostRegister); pageable memory works but serialises.  Returns when everything has completed.
+ * Cold start, full setup, batch-order dispatch; the results also stay on the device for mpcqp_get. */
+int mpcqp_solve_host(mpcqp_handle *h, const double *P, long strideP, const double *q, long strideq,
+                     const double *A, long strideA, const double *l, long stridel, const double *u, long strideu,
+                     double *x, double *y, int *status, int *iters, int chunks);
+
 /* Scheduling hint (on by default; MPCQP_NO_LPT=1 in the environment turns it off at create): after every solve the instances
  * are ranked by their ADMM iteration count, and the next solve on the handle hands them to workgroups in that order, longest
  * first.  Instances are independent, so no output changes by a bit; what changes is the tail of the launch -- with one QP per

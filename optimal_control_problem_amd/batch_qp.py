@@ -136,6 +136,28 @@ class BatchQP:
     def solve(self, stream=None):
         _lib.check(_lib.lib().mpcqp_solve(self._h, stream))
 
+    def solve_host(self, P, q, A, l, u, chunks=0, out=None):
+        """fused, pipelined host-buffer step (mpcqp_solve_host): NumPy arrays or CPU torch tensors, ideally pinned; returns
+        dict x, y, status, iters (pinned torch-backed NumPy arrays when torch is available, reused through `out`)"""
+        B = self.batch
+        items = [_ptr_stride(P, self.nnzP, B, "P"), _ptr_stride(q, self.n, B, "q"), _ptr_stride(A, self.nnzA, B, "A"),
+                 _ptr_stride(l, self.m, B, "l"), _ptr_stride(u, self.m, B, "u")]
+        if any(it[2] != _lib.MEM_HOST for it in items):
+            raise ValueError("solve_host takes host arrays")
+        if out is None:
+            try:
+                import torch
+                mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory().numpy()
+                out = dict(x=mk((B, self.n), torch.float64), y=mk((B, self.m), torch.float64), status=mk((B,), torch.int32), iters=mk((B,), torch.int32))
+            except (ImportError, RuntimeError):
+                out = dict(x=np.empty((B, self.n)), y=np.empty((B, self.m)), status=np.empty(B, np.int32), iters=np.empty(B, np.int32))
+        args = []
+        for ptr, stride, _, _ in items:
+            args += [ptr, stride]
+        _lib.check(_lib.lib().mpcqp_solve_host(self._h, *args, out["x"].ctypes.data, out["y"].ctypes.data, out["status"].ctypes.data,
+                                               out["iters"].ctypes.data, int(chunks)))
+        return out
+
     def sync(self):
         _lib.check(_lib.lib().mpcqp_sync(self._h))
 

@@ -1461,6 +1461,10 @@ struct mpcqp_handle {
   double *dx0 = nullptr, *dy0 = nullptr, *drho0 = nullptr;
   bool keep = false, have_factor = false, reuse_next = false;
   int *order[2] = {nullptr, nullptr}; int order_cur = -1; bool lpt = true; hipEvent_t ev_order = nullptr;   // dispatch hint, double-buffered
+  static constexpr int NPIPE = 8;
+  hipStream_t pipe[NPIPE] = {};               // mpcqp_solve_host: compute streams, one per slice in flight
+  hipStream_t pipe_copy = nullptr;            // ... and the one stream all host-to-device copies queue on, in slice order
+  std::vector<hipEvent_t> pipe_ev;            // slice k's inputs have landed
   double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oinfo = nullptr, *ocs = nullptr; int *ostatus = nullptr, *oiters = nullptr;
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
@@ -1793,6 +1797,84 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   return MPCQP_OK;
 }
 
+// launch of instances [b0, b0 + count) on stream s: every per-instance pointer of `io` is advanced, the kernels index by blockIdx
+static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_t s) {
+  const long n = h->n, m = h->m;
+  io.P += (long)b0 * io.sP; io.q += (long)b0 * io.sq; io.A += (long)b0 * io.sA; io.l += (long)b0 * io.sl; io.u += (long)b0 * io.su;
+  if (io.x0) io.x0 += b0 * n;
+  if (io.y0) io.y0 += b0 * m;
+  if (io.rho0) io.rho0 += b0;
+  io.x += b0 * n; io.y += b0 * m; io.z += b0 * m; io.status += b0; io.iters += b0; io.info += 4L * b0;
+  io.ws += (long)b0 * h->dp.ws_stride; io.cscale += b0;
+  if (io.dbg) io.dbg += 16L * b0;
+  io.order = nullptr;
+  if (h->variant > 0) {
+    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
+    HIPCHK(hipLaunchKernel(res_kernel_of(h, false), dim3(count), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
+  }
+  else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  HIPCHK(hipGetLastError());
+  return MPCQP_OK;
+}
+
+int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q, long sq, const double *A, long sA,
+                     const double *l, long sl, const double *u, long su,
+                     double *x, double *y, int *status, int *iters, int chunks) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!q || (h->plan.nnzP_in > 0 && !P) || (h->plan.nnzA_in > 0 && !A) || (h->m > 0 && (!l || !u))) return fail(MPCQP_ERR_ARG, "null data pointer");
+  const long wP = h->plan.nnzP_in, wA = h->plan.nnzA_in, n = h->n, m = h->m;
+  if ((sP && sP != wP) || sq != n || (sA && sA != wA) || (m > 0 && (sl != m || su != m)))
+    return fail(MPCQP_ERR_ARG, "dimension mismatch: mpcqp_solve_host takes dense instance-major arrays (stride = width; 0 shares P or A)");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->last_stream || h->solved) HIPCHK(hipStreamSynchronize(h->last_stream));
+  chunks = std::max(1, std::min(chunks > 0 ? chunks : 6, h->batch));
+  int rc;
+  const size_t B = h->batch;
+  if (!h->dP) { if ((rc = dalloc(h, &h->dP, (size_t)std::max<long>(wP, 1) * B))) return rc; }
+  if (!h->dq) { if ((rc = dalloc(h, &h->dq, (size_t)n * B))) return rc; }
+  if (!h->dA) { if ((rc = dalloc(h, &h->dA, (size_t)std::max<long>(wA, 1) * B))) return rc; }
+  if (!h->dl) { if ((rc = dalloc(h, &h->dl, (size_t)std::max<long>(m, 1) * B))) return rc; }
+  if (!h->du) { if ((rc = dalloc(h, &h->du, (size_t)std::max<long>(m, 1) * B))) return rc; }
+  // a slice's kernel ends with a tail (its slowest instance); several slices in flight fill each other's tails
+  const int ns = std::min(chunks, mpcqp_handle::NPIPE);
+  for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
+  DevIO io = h->io;
+  io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.reuse = 0; io.keep = h->keep ? 1 : 0; io.order = nullptr;
+  if (sP == 0 && wP) HIPCHK(hipMemcpy(h->dP, P, wP * sizeof(double), hipMemcpyHostToDevice));      // shared matrices: once
+  if (sA == 0 && wA) HIPCHK(hipMemcpy(h->dA, A, wA * sizeof(double), hipMemcpyHostToDevice));
+  if (!h->pipe_copy) HIPCHK(hipStreamCreateWithFlags(&h->pipe_copy, hipStreamNonBlocking));
+  while ((int)h->pipe_ev.size() < chunks) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->pipe_ev.push_back(e); }
+  for (int c = 0; c < chunks; c++) {
+    const int b0 = (int)((long)h->batch * c / chunks), b1 = (int)((long)h->batch * (c + 1) / chunks), cnt = b1 - b0;
+    if (cnt <= 0) continue;
+    // inputs of all slices queue on ONE stream, in slice order, so that slice 0 is complete after 1/chunks of the transfer
+    // (copies spread over several streams share the link and all finish late)
+    hipStream_t cs = h->pipe_copy, s = h->pipe[c % ns];
+    if (sP) HIPCHK(hipMemcpyAsync(h->dP + (size_t)b0 * wP, P + (size_t)b0 * wP, (size_t)cnt * wP * sizeof(double), hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(h->dq + (size_t)b0 * n, q + (size_t)b0 * n, (size_t)cnt * n * sizeof(double), hipMemcpyHostToDevice, cs));
+    if (sA) HIPCHK(hipMemcpyAsync(h->dA + (size_t)b0 * wA, A + (size_t)b0 * wA, (size_t)cnt * wA * sizeof(double), hipMemcpyHostToDevice, cs));
+    if (m) {
+      HIPCHK(hipMemcpyAsync(h->dl + (size_t)b0 * m, l + (size_t)b0 * m, (size_t)cnt * m * sizeof(double), hipMemcpyHostToDevice, cs));
+      HIPCHK(hipMemcpyAsync(h->du + (size_t)b0 * m, u + (size_t)b0 * m, (size_t)cnt * m * sizeof(double), hipMemcpyHostToDevice, cs));
+    }
+    HIPCHK(hipEventRecord(h->pipe_ev[c], cs));
+    HIPCHK(hipStreamWaitEvent(s, h->pipe_ev[c], 0));
+    if ((rc = launch_slice(h, io, b0, cnt, s))) return rc;
+    if (x) HIPCHK(hipMemcpyAsync(x + (size_t)b0 * n, h->ox + (size_t)b0 * n, (size_t)cnt * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (y && m) HIPCHK(hipMemcpyAsync(y + (size_t)b0 * m, h->oy + (size_t)b0 * m, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (status) HIPCHK(hipMemcpyAsync(status + b0, h->ostatus + b0, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (iters) HIPCHK(hipMemcpyAsync(iters + b0, h->oiters + b0, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(h->pipe_copy));
+  for (int i = 0; i < ns; i++) HIPCHK(hipStreamSynchronize(h->pipe[i]));
+  h->io.P = io.P; h->io.sP = io.sP; h->io.q = io.q; h->io.sq = io.sq; h->io.A = io.A; h->io.sA = io.sA; h->io.l = io.l; h->io.sl = io.sl; h->io.u = io.u; h->io.su = io.su;
+  h->have_data = true; h->reuse_next = false; h->solved = true; h->have_factor = h->keep; h->last_stream = nullptr; h->order_cur = -1;
+  return MPCQP_OK;
+}
+
 int mpcqp_get(mpcqp_handle *h, double *x, double *y, double *z, int *status, int *iters, double *info, int mem) {
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
   if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
@@ -1825,6 +1907,9 @@ void mpcqp_destroy(mpcqp_handle *h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+  for (int i = 0; i < mpcqp_handle::NPIPE; i++) if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);
+  if (h->pipe_copy) (void)hipStreamDestroy(h->pipe_copy);
+  for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
   delete h;
 }
 

@@ -503,3 +503,31 @@ def test_random_sparse_patterns(built, monkeypatch, variant):
         ref = problems.oracle_solve(ls)
         assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all(), (c, n, m, B, dens)
         _close(got, ref, "x")
+
+
+def test_pipelined_host_step(built):
+    """mpcqp_solve_host (fused setSystem + initSolver + solve + getSolution over pipelined batch slices) returns exactly what
+    update + solve + get return, for pinned and pageable inputs, odd slice counts, shared matrices and after other solves"""
+    import torch
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("cartpole", 333, N=30)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); ref = qp.get()
+    pin = [torch.from_numpy(a).pin_memory() for a in (ls.P, ls.q, ls.A, ls.l, ls.u)]
+    for chunks, args in ((0, pin), (7, pin), (1, pin), (1000, (ls.P, ls.q, ls.A, ls.l, ls.u))):
+        got = qp.solve_host(*args, chunks=chunks)
+        for k in ("x", "y", "status", "iters"):
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (chunks, k)
+    after = qp.get()                                     # results also stay on the device
+    assert np.array_equal(after["x"], ref["x"]) and np.array_equal(after["z"], ref["z"])
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); again = qp.get()
+    assert np.array_equal(again["x"], ref["x"])
+    qp.close()
+    mdl, ld, _ = models.make_workload("double_integrator", 50)
+    qd = BatchQP(ld.n, ld.m, 50, ld.Pp, ld.Pi, ld.Ap, ld.Ai)
+    qd.update(ld.P[0], ld.q, ld.A[0], ld.l, ld.u); qd.solve(); r0 = qd.get()
+    g0 = qd.solve_host(ld.P[0], ld.q, ld.A[0], ld.l, ld.u, chunks=3)            # matrices shared by the batch (stride 0)
+    assert np.array_equal(g0["x"], r0["x"]) and np.array_equal(g0["iters"], r0["iters"])
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        qd.solve_host(ld.P[0], ld.q[:, :-1], ld.A[0], ld.l, ld.u)
+    qd.close()
