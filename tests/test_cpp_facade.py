@@ -21,3 +21,22 @@ def test_cpp_facade_on_gpu(built):
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "status 1 iters 25" in r.stdout
+
+
+SQP_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "stagesqp_cpp_test")
+
+
+def test_cpp_stage_sqp_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; see the gpu-marked test")
+    r = subprocess.run([SQP_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)       # refused loudly, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_cpp_stage_sqp_on_gpu(built):
+    """StageSQP.hpp: the device-resident SQP loop written against the C ABI in C++"""
+    r = subprocess.run([SQP_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "max dynamics violation" in r.stdout
