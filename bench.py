@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="QP instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=None, help="QPs timed on the host for cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="timed region only: skip the in-order, PCIe-inclusive and CPU-baseline legs (profiling runs)")
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
     ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4"])
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 flow on a one-GPU box: all ranks use cuda:0, collectives over gloo")
@@ -184,7 +185,7 @@ def main():
                                                "LDL' %d waves/QP, factor blocks streamed from HBM" % (pinfo["variant"] - 100) if pinfo["variant"] >= 100 else
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
-        if world == 1 and not args.force_iters:
+        if world == 1 and not args.force_iters and not args.no_extras:
             # the same step with the dispatch hint off (instances handed to workgroups in batch order, as a first solve on a
             # fresh handle does): separates the kernel from the scheduling gain.  `value` is the default behaviour (hint on).
             qp.set_dispatch_hint(False)
@@ -228,7 +229,7 @@ def main():
             assert np.array_equal(res["x"], hx) and np.array_equal(res["iters"], hit)       # same results as the unpipelined step
             out["pcie_inclusive_pipelined"] = {"value": batch / best[0], "unit": "QP solves/s", "ms_per_step": best[0] * 1e3, "chunks": best[1],
                                                "note": "mpcqp_solve_host: pinned host buffers; slices of the batch are copied in on one stream while earlier slices are solved and copied out on others"}
-        if world == 1 and not args.no_cpu_baseline and not args.force_iters:
+        if world == 1 and not args.no_cpu_baseline and not args.force_iters and not args.no_extras:
             # the oracle (CPU port of the same algorithm) on this box's host cores, bounded sample of the same workload
             from oracle import oracle as orc
             cores = int(os.environ.get("MPCQP_CPU_THREADS", "0")) or host_cores()
