@@ -861,7 +861,7 @@ __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int
   }
   return acc;
 }
-template <int NW, bool GB>
+template <int NW, bool GB, int PD = 6>
 __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane, long long *trace = nullptr) {
   const int r = lane >> 2, j = lane & 3;
   const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
@@ -873,9 +873,9 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
     const int db = __builtin_amdgcn_readfirstlane(c.y), ds = __builtin_amdgcn_readfirstlane(c.z), dd = __builtin_amdgcn_readfirstlane(c.w);
     if (fl & SG_NOP) { bsync<NW>(); continue; }
     if (GB && (fl & SG_EACH)) {
-      if (fl & SG_SET) seg_each_g<false, true, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, 0.0);
-      else if (fl & SG_T) seg_each_g<true, false, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
-      else seg_each_g<false, false, 6>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      if (fl & SG_SET) seg_each_g<false, true, PD>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, 0.0);
+      else if (fl & SG_T) seg_each_g<true, false, PD>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
+      else seg_each_g<false, false, PD>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
       acc = 0.0;
     } else if ((fl & (SG_EACH | SG_IND)) == (SG_EACH | SG_IND)) {
       if (fl & SG_SET) seg_each2<false, true>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j);
@@ -1151,6 +1151,7 @@ template <int NW, int MINW, bool GB, bool REUSE>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
+  constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
   constexpr int EU = 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower)
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
@@ -1308,10 +1309,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
 #ifdef MPCQP_TIMING
       long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
       if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
-      run_schedule<NW, GB>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
+      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
       if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
 #else
-      run_schedule<NW, GB>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
 #endif
       if (NW == 1) bsync<NW>();
       TS(5);
@@ -1452,6 +1453,7 @@ struct mpcqp_handle {
   int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
   bool wide = false;            // resident kernel instance that may use the whole register file (one QP per CU)
   bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
+  bool occ3 = false;            // ... its 168-VGPR instance (exactly 3 workgroups per CU fit in LDS), 8 blocks in flight
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
@@ -1504,6 +1506,7 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
   if (h->variant == 1) return (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
   if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
@@ -1605,6 +1608,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       h->rplan = build_res_plan(pl, want);
       const long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
       h->occ4 = h->gblocks && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
+      // LDS between 40 and 53 KiB: three workgroups per CU fit, so the instance compiled for three waves per SIMD (168 VGPRs, no
+      // spills, 8 blocks in flight) replaces the 128-VGPR one (cart-pole N=100: 92.9k -> 95.8k QP/s; at 32 KiB it loses, 589k -> 551k)
+      h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
       if (const char *pad = getenv("MPCQP_LDS_MIN")) h->lds = std::max<long>(h->lds, atol(pad));   // experiment: limit workgroups per CU
