@@ -14,6 +14,8 @@ from optimal_control_problem_amd._lib import Settings
 
 torch.zeros(1, device="cuda")
 cases = [("quadrotor", 20, 8192), ("cartpole", 30, 8192), ("double_integrator", 20, 4096)]
+if os.environ.get("AB_CASES"):      # e.g. AB_CASES=quadrotor:50:4096,cartpole:100:8192
+    cases = [(c.split(":")[0], int(c.split(":")[1]), int(c.split(":")[2])) for c in os.environ["AB_CASES"].split(",")]
 data = {}
 for name, N, B in cases:
     mdl, ls, _ = models.make_workload(name, B, N=N)
