@@ -49,7 +49,7 @@ struct DevPlan {
   const int *pos, *perm, *fwd_ops, *bwd_ops, *bwd_of;
   const int4 *fac;
   const int *tpos, *asm_ptr, *asm_a, *asm_b, *asm_pidx, *blk_diag;
-  long o_ellA, o_ellAt, o_ellP, o_Lf, o_Lb, o_T, o_l, o_u, o_D, o_E, o_dx, o_dy, ws_stride;
+  long o_ellA, o_ellAt, o_ellP, o_Lf, o_Lb, o_T, o_l, o_u, o_D, o_E, o_dx, o_dy, ws_stride, o_Zg, o_Yg;
 };
 struct DevIO {
   const double *P, *q, *A, *l, *u; long sP, sq, sA, sl, su;
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 // CU anyway (the kernel may then use the whole register file), 2 otherwise
 // GB = the factor blocks stay in the per-QP HBM slab (factors that do not fit LDS); LDS then holds only the temp
 // tiles, the ADMM vectors and the schedule, and the segment loops keep several blocks in flight.
-template <int NW, int MINW, bool GB, bool REUSE>
+template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
@@ -1163,7 +1163,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (GB) { cx.BL = ws + pl.o_Lf; cx.TMP = lds; }
   else { cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK; }
   cx.X = lds + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
-  cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad;
+  if (GB && ZYG) {   // z and y are only ever indexed by their own row: in the slab they cost two coalesced streams per iteration and
+    cx.Z = ws + pl.o_Zg; cx.Y = ws + pl.o_Yg; cx.W = cx.R + pl.npad;   // free 2 * mpad doubles of LDS (one more workgroup per CU for long horizons)
+  } else { cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad; }
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
@@ -1327,11 +1329,13 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         for (int c = wid; c < pl.A.nchunks; c += NW) {
           const int i = c * WAVE + lane;
           const double lo = lb[i], up = ub[i];
+          // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
+          const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
           const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, pl.A.chunk_off[c], pl.A.chunk_off[c + 1], lane);
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
-            const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
+            const double zr = alpha * zt + (1.0 - alpha) * ((GB && ZYG) ? zo : cx.Z[i]), yo = (GB && ZYG) ? yp : cx.Y[i];
             const double zn = fmin(fmax(zr + rinv * yo, lo), up);
             const double dy = rh * (zr - zn), yn = yo + dy;
             cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
@@ -1453,6 +1457,7 @@ struct mpcqp_handle {
   int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
   bool wide = false;            // resident kernel instance that may use the whole register file (one QP per CU)
   bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
+  bool zyg = false;             // ... with z, y in the slab instead of LDS (lifts workgroups per CU for long horizons)
   bool occ3 = false;            // ... its 168-VGPR instance (exactly 3 workgroups per CU fit in LDS), 8 blocks in flight
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   ResPlan rplan; DevRes dres;
@@ -1506,6 +1511,7 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
   if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
   if (h->variant == 1) return (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
@@ -1599,18 +1605,24 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       else if (small_ok && l1 <= 40 * 1024) want = 1;
       else {
         if (small_ok && l4 <= 80 * 1024) want = 4;
-        else if (small_ok && lds_bytes_res_gb(p4, r4) <= LDS_MAX) { want = 4; h->gblocks = true; }
+        else if (small_ok && lds_bytes_res_gb(p4, r4, !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
         else want = 0;
       }
     }
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want);
-      const long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
-      h->occ4 = h->gblocks && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
+      long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      if (h->gblocks && !getenv("MPCQP_NO_ZYG")) {
+        // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
+        const long alt = lds_bytes_res_gb(pl, h->rplan, true);
+        const long fit = LDS_MAX / need, fit_alt = std::min<long>(LDS_MAX / alt, 3);
+        if (fit <= 2 && fit_alt > fit) { h->zyg = true; need = alt; }
+      }
+      h->occ4 = h->gblocks && !h->zyg && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
       // LDS between 40 and 53 KiB: three workgroups per CU fit, so the instance compiled for three waves per SIMD (168 VGPRs, no
       // spills, 8 blocks in flight) replaces the 128-VGPR one (cart-pole N=100: 92.9k -> 95.8k QP/s; at 32 KiB it loses, 589k -> 551k)
-      h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
+      h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
       if (const char *pad = getenv("MPCQP_LDS_MIN")) h->lds = std::max<long>(h->lds, atol(pad));   // experiment: limit workgroups per CU
@@ -1644,7 +1656,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
-  dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.ws_stride = w.stride;
+  dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.o_Zg = w.Zg; dp.o_Yg = w.Yg; dp.ws_stride = w.stride;
   UP(dalloc(h, &h->ws, (size_t)w.stride * batch));
   UP(dalloc(h, &h->ox, (size_t)batch * n)); UP(dalloc(h, &h->oy, (size_t)batch * std::max(m, 1))); UP(dalloc(h, &h->oz, (size_t)batch * std::max(m, 1)));
   UP(dalloc(h, &h->oinfo, (size_t)batch * 4)); UP(dalloc(h, &h->ocs, (size_t)batch));

@@ -377,7 +377,7 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
 
 // workspace layout per QP, in doubles; every section starts on a 16-double (128 B) boundary
 struct WsLayout {
-  long ellA, ellAt, ellP, Lf, Lb, T, l, u, D, E, dx, dy, stride;
+  long ellA, ellAt, ellP, Lf, Lb, T, l, u, D, E, dx, dy, Zg, Yg, stride;
 };
 inline WsLayout ws_layout(const Plan &pl) {
   WsLayout w; long o = 0;
@@ -386,6 +386,7 @@ inline WsLayout ws_layout(const Plan &pl) {
   w.Lf = take((long)pl.nblk * BLK); w.Lb = take((long)pl.nblk * BLK); w.T = take((long)std::max(pl.nT, 1) * BLK);
   w.l = take(pl.mpad); w.u = take(pl.mpad); w.D = take(pl.npad); w.E = take(pl.mpad);
   w.dx = take(pl.npad); w.dy = take(pl.mpad);
+  w.Zg = take(pl.mpad); w.Yg = take(pl.mpad);   // z, y of the kernels that keep them out of LDS (row-indexed only, like l and u)
   w.stride = o;
   return w;
 }
@@ -618,9 +619,10 @@ inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
 }
 // the same kernels with the factor blocks left in the HBM slab: LDS holds temp tiles + vectors + schedule only
 inline long res_stage_doubles_gb(const ResPlan &rp) { return ((long)rp.ntemp * BLK + 15) / 16 * 16; }
-inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp) {
+// zy_global: z and y live in the slab as well (they are only ever indexed by their own row, so wave accesses are contiguous)
+inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp, bool zy_global = false) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;
-  return (res_stage_doubles_gb(rp) + 3L * pl.npad + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles_gb(rp) + 3L * pl.npad + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
 }
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles

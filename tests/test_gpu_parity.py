@@ -531,3 +531,14 @@ def test_pipelined_host_step(built):
     with pytest.raises(ValueError, match="dimension mismatch"):
         qd.solve_host(ld.P[0], ld.q[:, :-1], ld.A[0], ld.l, ld.u)
     qd.close()
+
+
+@pytest.mark.parametrize("name,N,B", [("quadrotor", 50, 40), ("quadrotor", 100, 12), ("cartpole", 100, 30)])
+def test_long_horizons_vs_oracle(built, name, N, B):
+    """long horizons run the global-block kernels, the longest ones with z and y in the slab as well (one more workgroup per
+    CU): same bar"""
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    _compare(ls)
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    qp = BatchQP(ls.n, ls.m, 4096, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+    assert info["variant"] >= 100
