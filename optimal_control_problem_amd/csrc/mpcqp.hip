@@ -4,17 +4,22 @@
 // CuCaQP::setSystem -> initSolver -> solve -> getSolution (reference src/sqp_solver/CuCaQP.cpp:271-288,
 // 183-224), i.e. OSQP's osqp_setup + osqp_solve (external to the reference, see oracle/osqp_oracle.h).
 //
-// Execution model: ONE QP PER WAVEFRONT (64-thread workgroup, no inter-wave synchronisation at all).
-//   * ADMM iterates x, q, rhs [npad] and z, y, rho*z-y [mpad] live in LDS for the whole solve;
-//   * matrix data (scaled A in two ELL orientations, scaled P, the block Cholesky factor of
-//     M = P + sigma I + A' diag(rho) A in forward and transposed-backward stream order) lives in a per-QP
-//     HBM slab and is streamed with fully coalesced 512 B / 2 KiB wave loads;
-//   * the linear solve is a stream of 16x16 block mat-vecs: 4 lanes per row, quad-shuffle reduction;
-//   * the factorisation's block products (assembly of M, Schur updates, L_IJ = S_IJ Linv_JJ') are real dense
-//     16x16x16 GEMMs and run on the matrix cores (v_mfma_f64_16x16x4_f64); the 16x16 Cholesky + triangular
-//     inverse runs in LDS;
-//   * box projection, dual update and all residual norms are fused into the ELL sweeps and reduced with
-//     wavefront shuffles.
+// One launch does the whole sequence for every QP of the batch (grid = batch, one workgroup per QP).  Kernel families
+// (mpcqp_create picks one per sparsity and batch size from measured rules):
+//   * mpcqp_res_kernel<NW, MINW, GB, REUSE, ZYG> -- NW wavefronts per QP (1 or 4), W-fused block LDL' of
+//     M = P + sigma I + A' diag(rho) A in 16x16 blocks, solve driven by a host-built schedule of arithmetic-progression
+//     segments (plan.hpp).  GB = false: the factor lives in LDS (small / mid-size problems, and any batch that fits one
+//     resident round); GB = true: the factor stays in the per-QP HBM slab and LDS holds only vectors, temp tiles and the
+//     schedule, so that 3-4 workgroups share a CU (the default for the 12-state quadrotor sizes; HBM-roofline-bound).
+//     MINW selects the register budget (128 / 168 / 256 VGPRs), REUSE the kept-workspace entry (mpcqp_update_vectors),
+//     ZYG keeps z and y in the slab too (long horizons).
+//   * mpcqp_admm_kernel<PD> -- the first-generation streaming kernel, one QP per wavefront, block Cholesky streamed from
+//     the slab; fallback when even the vectors exceed LDS, and a cross-check in the variant tests.
+// Common to all: ADMM iterates in LDS; scaled A in two ELL orientations and scaled P in the slab, streamed with coalesced
+// 512 B wave loads; the linear solve is a stream of 16x16 block mat-vecs (4 lanes per row, quad DPP reduction); the
+// factorisation's block products are dense 16x16x16 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64); box projection,
+// dual update and residual norms fused into the ELL sweeps; termination, infeasibility certificates and adaptive-rho
+// re-factorisation in-kernel; workgroup-uniform state in scalar registers (uni()).
 // Numerics are fp64 throughout and follow oracle/osqp_oracle.c step by step (same scaling rule, rho rule,
 // termination / infeasibility tests and deterministic adaptive-rho schedule).
 #include <hip/hip_runtime.h>
