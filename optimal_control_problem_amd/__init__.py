@@ -5,7 +5,8 @@ Importing the package never touches the GPU; the first compute call loads libmpc
 the library or a gfx950 device is missing (there is no CPU fallback)."""
 from . import models  # noqa: F401
 
-__all__ = ["models", "BatchQP", "CuCaQP", "SQPOptimizationSolver"]
+__all__ = ["models", "BatchQP", "CuCaQP", "SQPOptimizationSolver", "DeviceSQPOptimizationSolver", "StageEvaluator",
+           "OptimalControlProblem", "OCPConfig"]
 
 
 def __getattr__(name):
@@ -15,7 +16,13 @@ def __getattr__(name):
     if name == "CuCaQP":
         from .cucaqp import CuCaQP
         return CuCaQP
-    if name == "SQPOptimizationSolver":
-        from .sqp import SQPOptimizationSolver
-        return SQPOptimizationSolver
+    if name in ("SQPOptimizationSolver", "DeviceSQPOptimizationSolver"):
+        from . import sqp
+        return getattr(sqp, name)
+    if name == "StageEvaluator":
+        from .stage_eval import StageEvaluator
+        return StageEvaluator
+    if name in ("OptimalControlProblem", "OCPConfig"):
+        from . import ocp
+        return getattr(ocp, name)
     raise AttributeError(name)
