@@ -248,6 +248,10 @@ def main():
             out["cpu_baseline"] = {"value": ns / tc, "unit": "QP solves/s", "cores": cores, "kind": "port",
                                    "sample": "first %d QPs of the same batch, OpenMP over instances, sparse LDL' per QP "
                                              "(symbolic analysis shared), %d repetitions, %.2f s wall each, logical CPUs on the box %d" % (ns, reps, tc, os.cpu_count() or 0)}
+            # one host thread, one QP at a time -- how the reference itself runs (SURVEY.md section 8d baseline (a))
+            n1 = min(ns, 512)
+            t1 = time.perf_counter(); pat.solve(ls.P[:n1], ls.q[:n1], ls.A[:n1], ls.l[:n1], ls.u[:n1], st, nthreads=1); t1 = time.perf_counter() - t1
+            out["cpu_baseline"]["single_thread"] = {"value": n1 / t1, "unit": "QP solves/s", "cores": 1, "sample": "first %d QPs, %.2f s" % (n1, t1)}
             out["parity"] = {"max_abs_x_err_vs_oracle": float(np.abs(xg[fin] - ref["x"][fin]).max()),
                              "iters_equal": bool((iters[:ns] == ref["iters"]).all()),
                              "status_equal": bool((status[:ns] == ref["status"]).all())}
