@@ -208,6 +208,10 @@ int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out);
  * nx <= 16, nu <= 8. */
 int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path, mpcqp_stage **out);
 void mpcqp_stage_destroy(mpcqp_stage *s);
+/* Per-frame diagonal weights (terminal costs, ramps): Qk [horizon * nx], Rk [horizon * nu], host pointers, copied; frame k is
+ * weighted by Qk[k*nx ...], Rk[k*nu ...] instead of desc.Q, desc.R (the reference calls addVectorCost once per step, so weights may
+ * differ by step, reference readme.md:121-128).  NULL, NULL returns to desc.Q, desc.R. */
+int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk);
 /* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
 int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);
 /* CSC sparsity of P (n x n, both triangles, as CasADi hands it to CuCaQP) and A = [I; dg/dw] (m x n): the arrays

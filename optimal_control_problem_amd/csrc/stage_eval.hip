@@ -28,6 +28,7 @@ struct mpcqp_stage {
   int device = 0;
   std::vector<int> Pp, Pi, Ap, Ai;
   int *dPp = nullptr, *dAp = nullptr;
+  double *dQk = nullptr, *dRk = nullptr;
   void *user_lib = nullptr;           // dlopen handle of a generated dynamics library (model == MPCQP_MODEL_USER)
   user_eval_fn user_eval = nullptr;
   user_merit_fn user_merit = nullptr;
@@ -104,7 +105,7 @@ static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh
   if (hipMemcpy(s->dPp, s->Pp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->dAp, s->Ap.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
     return mpcqp_set_error(MPCQP_ERR_HIP, "upload of the column pointers failed");
-  sd.Pp = s->dPp; sd.Ap = s->dAp;
+  sd.Pp = s->dPp; sd.Ap = s->dAp; sd.Qk = nullptr; sd.Rk = nullptr;
   return MPCQP_OK;
 }
 
@@ -158,8 +159,25 @@ void mpcqp_stage_destroy(mpcqp_stage *s) {
   (void)hipSetDevice(s->device);
   if (s->dPp) (void)hipFree(s->dPp);
   if (s->dAp) (void)hipFree(s->dAp);
+  if (s->dQk) (void)hipFree(s->dQk);
+  if (s->dRk) (void)hipFree(s->dRk);
   if (s->user_lib) dlclose(s->user_lib);
   delete s;
+}
+
+int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk) {
+  if (!s) return mpcqp_set_error(MPCQP_ERR_ARG, "stage handle is null");
+  if ((Qk == nullptr) != (Rk == nullptr)) return mpcqp_set_error(MPCQP_ERR_ARG, "give both weight arrays or neither");
+  MPCQP_HIPCHK(hipSetDevice(s->device));
+  StageDev &sd = s->sd;
+  if (!Qk) { sd.Qk = nullptr; sd.Rk = nullptr; return MPCQP_OK; }
+  const size_t bq = (size_t)sd.N * sd.nx * sizeof(double), br = (size_t)sd.N * sd.nu * sizeof(double);
+  if (!s->dQk) MPCQP_HIPCHK(hipMalloc(&s->dQk, bq));
+  if (!s->dRk) MPCQP_HIPCHK(hipMalloc(&s->dRk, br));
+  MPCQP_HIPCHK(hipMemcpy(s->dQk, Qk, bq, hipMemcpyHostToDevice));
+  MPCQP_HIPCHK(hipMemcpy(s->dRk, Rk, br, hipMemcpyHostToDevice));
+  sd.Qk = s->dQk; sd.Rk = s->dRk;
+  return MPCQP_OK;
 }
 
 int mpcqp_stage_dims(const mpcqp_stage *s, int *o) {

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "stage_models.hpp"
 
-#define STAGE_ABI_VERSION 2
+#define STAGE_ABI_VERSION 3
 
 struct StageDev {
   int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows
@@ -16,6 +16,7 @@ struct StageDev {
   double dt;
   double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
   const int *Pp, *Ap;   // device copies of the column pointers
+  const double *Qk, *Rk;   // optional per-frame diagonal weights [N * nx], [N * nu] (device; NULL = Q, R for every frame)
 };
 
 template <class M>
@@ -34,10 +35,17 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   double *qb = q + (long)b * n, *lb = l + (long)b * sd.m, *ub = u + (long)b * sd.m;
   if (j < nx) {
     // column p_i: H = d2f/dp_i2 = 2 N Q_i, d2f/dp_i ds_k[i] = -2 Q_i; grad = -2 Q_i sum_k (s_k[i] - p_i); rows l = u = p - p
-    const double Qi = sd.Q[j], pi = pb[j];
+    const double pi = pb[j];
     double e = 0.0;
-    Pc[0] = 2.0 * N * Qi;
-    for (int k = 0; k < N; k++) { Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
+    if (sd.Qk) {   // per-frame weights: d2f/dp_i2 = 2 sum_k Q_k,i
+      double qs = 0.0;
+      for (int k = 0; k < N; k++) { const double Qi = sd.Qk[k * nx + j]; qs += Qi; Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
+      Pc[0] = 2.0 * qs;
+    } else {
+      const double Qi = sd.Q[j];
+      Pc[0] = 2.0 * N * Qi;
+      for (int k = 0; k < N; k++) { Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
+    }
     qb[j] = -2.0 * e;
     Ac[0] = 1.0;
     lb[j] = pi - pi; ub[j] = pi - pi;
@@ -47,11 +55,11 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   const double *fr = xb + k * f;
   const double xv = fr[c];
   if (c < nx) {
-    const double Qc = sd.Q[c];
+    const double Qc = sd.Qk ? sd.Qk[k * nx + c] : sd.Q[c];
     Pc[0] = -2.0 * Qc; Pc[1] = 2.0 * Qc;
     qb[j] = 2.0 * (xv - pb[c]) * Qc;
   } else {
-    const double Rc = sd.R[c - nx];
+    const double Rc = sd.Rk ? sd.Rk[k * nu + c - nx] : sd.R[c - nx];
     Pc[0] = 2.0 * Rc;
     qb[j] = 2.0 * xv * Rc;
   }
@@ -109,9 +117,9 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
     const double *fr = xb + k * f;
     double s[nx], uu[nu];
 #pragma unroll
-    for (int i = 0; i < nx; i++) { s[i] = fr[i]; const double e = s[i] - pb[i]; cost += e * e * sd.Q[i]; }
+    for (int i = 0; i < nx; i++) { s[i] = fr[i]; const double e = s[i] - pb[i]; cost += e * e * (sd.Qk ? sd.Qk[k * nx + i] : sd.Q[i]); }
 #pragma unroll
-    for (int i = 0; i < nu; i++) { uu[i] = fr[nx + i]; cost += uu[i] * uu[i] * sd.R[i]; }
+    for (int i = 0; i < nu; i++) { uu[i] = fr[nx + i]; cost += uu[i] * uu[i] * (sd.Rk ? sd.Rk[k * nu + i] : sd.R[i]); }
     if (k < sd.N - 1) {
       double out[nx];
       M::template F<double>(sd.par, sd.dt, s, uu, out);

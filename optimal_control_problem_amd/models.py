@@ -154,7 +154,11 @@ class StageOCP:
 
     def __init__(self, N, dt, Q, R):
         self.N, self.dt = int(N), float(dt)
+        # diagonal weights, the same for every frame ([nx], [nu]) or one row per frame ([N, nx], [N, nu]: terminal costs,
+        # ramps) -- addVectorCost is called per step in the reference (readme.md:121-128), so weights may differ by step
         self.Q = np.asarray(Q, float); self.R = np.asarray(R, float)
+        self.varying_weights = self.Q.ndim == 2 or self.R.ndim == 2
+        self.Qk = np.broadcast_to(self.Q, (int(N), self.nx)).copy(); self.Rk = np.broadcast_to(self.R, (int(N), self.nu)).copy()
         self.f = self.nx + self.nu
         self.np = self.nx
         self.nvar = self.N * self.f
@@ -242,6 +246,8 @@ class StageOCP:
     def objective(self, p, x):
         s, u = self.frames(x)
         e = s - p[:, None, :]
+        if self.varying_weights:
+            return np.einsum("bki,ki->b", e * e, self.Qk) + np.einsum("bki,ki->b", u * u, self.Rk)
         return np.einsum("bki,i->b", e * e, self.Q) + np.einsum("bki,i->b", u * u, self.R)
 
     def dh(self, s, u):
@@ -273,14 +279,14 @@ class StageOCP:
         e = s - p[:, None, :]
         # Hessian values are constant
         Pv = np.zeros(len(self.Pi))
-        Pv[self._P_pp] = 2.0 * N * self.Q
-        Pv[self._P_sp] = -2.0 * self.Q[None, :]; Pv[self._P_ps] = -2.0 * self.Q[None, :]
-        Pv[self._P_ss] = 2.0 * self.Q[None, :]; Pv[self._P_uu] = 2.0 * self.R[None, :]
+        Pv[self._P_pp] = 2.0 * self.Qk.sum(axis=0) if self.varying_weights else 2.0 * N * self.Q
+        Pv[self._P_sp] = -2.0 * self.Qk; Pv[self._P_ps] = -2.0 * self.Qk
+        Pv[self._P_ss] = 2.0 * self.Qk; Pv[self._P_uu] = 2.0 * self.Rk
         P = np.broadcast_to(Pv, (B, len(Pv))).copy()
         q = np.zeros((B, n))
-        q[:, :npp] = -2.0 * np.einsum("bki,i->bi", e, self.Q)
+        q[:, :npp] = -2.0 * (np.einsum("bki,ki->bi", e, self.Qk) if self.varying_weights else np.einsum("bki,i->bi", e, self.Q))
         qf = q[:, npp:].reshape(B, N, f)
-        qf[:, :, :nx] = 2.0 * e * self.Q; qf[:, :, nx:] = 2.0 * u * self.R
+        qf[:, :, :nx] = 2.0 * e * self.Qk; qf[:, :, nx:] = 2.0 * u * self.Rk
         J = self.dF(s[:, :-1, :], u[:, :-1, :])                 # [B, N-1, nx, f]
         A = np.zeros((B, len(self.Ai)))
         A[:, self._A_id] = 1.0

@@ -304,21 +304,19 @@ class OptimalControlProblem:
         for k, c in enumerate(dyn):
             if not (isinstance(c.a, Var) and c.a.step == k + 1 and c.a.name == s0.name and c.b.state.step == k and c.b.inp.step == k and c.b.F is F):
                 raise NotImplementedError("dynamics constraints must link frame k to frame k + 1 in order")
-        Q = np.zeros(nx); R = np.zeros(nu)
+        Qk = np.zeros((N, nx)); Rk = np.zeros((N, nu))        # per-step weights: terminal costs and ramps are ordinary here
         seenQ, seenR = set(), set()
         for kind, w, e in self.costs_:
             if kind != "weighted_square":
                 raise NotImplementedError("only addVectorCost terms are compiled")
             if isinstance(e, Diff) and isinstance(e.a, Var) and isinstance(e.b, Reference) and e.a.name == s0.name:
-                if seenQ and not np.array_equal(Q, w):
-                    raise NotImplementedError("state weights must be the same at every step")
-                Q = w; seenQ.add(e.a.step)
+                Qk[e.a.step] += w; seenQ.add(e.a.step)        # repeated terms on one step add up, like the SX sum (:491-497)
             elif isinstance(e, Var) and e.name == u0.name:
-                if seenR and not np.array_equal(R, w):
-                    raise NotImplementedError("input weights must be the same at every step")
-                R = w; seenR.add(e.step)
+                Rk[e.step] += w; seenR.add(e.step)
             else:
                 raise NotImplementedError("cost term not recognised")
+        same = (Qk == Qk[0]).all() and (Rk == Rk[0]).all()
+        Q, R = (Qk[0], Rk[0]) if same else (Qk, Rk)
         if seenQ != set(range(N)) or seenR != set(range(N)):
             raise NotImplementedError("tracking and input costs must be added for every step")
         if self.reference_ is None or self.reference_.size != nx:

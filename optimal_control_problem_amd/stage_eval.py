@@ -27,6 +27,7 @@ def _bind(L):
     L.mpcqp_stage_create_user.argtypes = [C.POINTER(StageDesc), C.c_char_p, C.POINTER(vp)]
     L.mpcqp_stage_destroy.argtypes = [vp]
     L.mpcqp_stage_destroy.restype = None
+    L.mpcqp_stage_set_weights.argtypes = [vp, dp, dp]
     L.mpcqp_stage_dims.argtypes = [vp, vp]
     L.mpcqp_stage_pattern.argtypes = [vp, vp, vp, vp, vp]
     L.mpcqp_stage_eval.argtypes = [vp, C.c_int] + [dp] * 11 + [vp]
@@ -64,16 +65,22 @@ class StageEvaluator:
         d = StageDesc()
         self.library = None
         if model is not None:
-            zoo = model.name in MODEL_IDS and type(model).__name__ in ("DoubleIntegrator", "Quadrotor", "CartPole")
+            from . import models as _m
+            # a zoo model is an instance of a zoo class whose dynamics are not overridden (weights, horizon, parameters may differ)
+            zoo = False
+            for cls in (_m.DoubleIntegrator, _m.Quadrotor, _m.CartPole):
+                if isinstance(model, cls) and model.name == cls.name and type(model).F is cls.F and type(model).cdyn is cls.cdyn:
+                    zoo = True
             use_codegen = (not zoo or model.nh > 0) if codegen is None else bool(codegen)
-            if model.nh > 0 and not use_codegen:
-                raise ValueError("a path constraint needs the generated evaluator (codegen=True)")
+            if not use_codegen and (model.nh > 0 or not zoo):
+                raise ValueError("this model needs the generated evaluator (codegen=True): it is not a built-in zoo model or has a path constraint")
             _lib.check(L.mpcqp_stage_default(MODEL_IDS.get(model.name, 0) if zoo else 0, int(model.N), C.byref(d)))
             d.dt = float(model.dt)
-            if len(model.Q) > 16 or len(model.R) > 8:
+            if model.nx > 16 or model.nu > 8:
                 raise ValueError("device evaluation supports nx <= 16 and nu <= 8")
-            for i in range(16): d.Q[i] = float(model.Q[i]) if i < len(model.Q) else 0.0
-            for i in range(8): d.R[i] = float(model.R[i]) if i < len(model.R) else 0.0
+            Q0, R0 = model.Qk[0], model.Rk[0]
+            for i in range(16): d.Q[i] = float(Q0[i]) if i < len(Q0) else 0.0
+            for i in range(8): d.R[i] = float(R0[i]) if i < len(R0) else 0.0
             for i in range(8): d.par[i] = 0.0
             if use_codegen:
                 from . import codegen as cg
@@ -90,6 +97,9 @@ class StageEvaluator:
             _lib.check(L.mpcqp_stage_create_user(C.byref(d), self.library.encode(), C.byref(self._h)))
         else:
             _lib.check(L.mpcqp_stage_create(C.byref(d), C.byref(self._h)))
+        if model is not None and getattr(model, "varying_weights", False):
+            Qk = np.ascontiguousarray(model.Qk, dtype=np.float64); Rk = np.ascontiguousarray(model.Rk, dtype=np.float64)
+            _lib.check(L.mpcqp_stage_set_weights(self._h, Qk.ctypes.data, Rk.ctypes.data))
         dims = np.zeros(8, np.int32)
         _lib.check(L.mpcqp_stage_dims(self._h, dims.ctypes.data))
         self.nx, self.nu, self.np, self.n, self.m, self.nnzP, self.nnzA, self.nvar = [int(v) for v in dims]

@@ -285,3 +285,56 @@ def test_facade_path_constraint(built):
     assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
     X = res["true"].reshape(B, 10, 4)
     assert (np.abs(X[:, 1:, 2] * X[:, 1:, 3]) <= 0.4 + 5e-2).all()
+
+
+def test_per_frame_weights_on_device(built):
+    """mpcqp_stage_set_weights (terminal cost / weight ramps): device evaluation and merit equal the host formulation, for a
+    built-in functor and for generated dynamics; the facade compiles per-step addVectorCost weights into them"""
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    N, B = 12, 24
+    rng = np.random.default_rng(1)
+    Qk = rng.uniform(0.1, 5.0, (N, 4)); Rk = rng.uniform(0.01, 1.0, (N, 1)); Qk[-1] *= 20.0
+
+    class CP(models.CartPole):
+        def __init__(self): models.StageOCP.__init__(self, N, 0.02, Qk, Rk)
+
+    mdl = CP()
+    x = rng.normal(0, 0.4, (B, mdl.nvar)); p = rng.normal(0, 0.3, (B, 4))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ref = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    for cg in (False, True):
+        ev = StageEvaluator(mdl, codegen=cg)
+        out = ev.eval(_dev(p), _dev(x), _dev(lbx), _dev(ubx), _dev(lbg), _dev(ubg))
+        for k, r in (("P", ref.P), ("q", ref.q), ("A", ref.A), ("l", ref.l), ("u", ref.u)):
+            assert _close(out[k].cpu().numpy(), r, 1e-12), (cg, k)
+        f, _ = ev.merit(_dev(p), _dev(x))
+        assert _close(f.cpu().numpy(), mdl.objective(p, x), 1e-12)
+        ev.close()
+    # facade: a terminal weight through per-step addVectorCost, device-resident = host
+    import yaml
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem
+    text = """
+      discretization_settings: {dt: 0.05, horizon: 10}
+      solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 1.0, step_num: 2}}
+      OCP_variables:
+        - {name: state, size: 2, lower_bound: [-.inf, -2.0], upper_bound: [.inf, 2.0]}
+        - {name: input, size: 1, lower_bound: [-1.0], upper_bound: [1.0]}
+    """
+    F = lambda s, u: np.stack([s[..., 0] + 0.05 * s[..., 1] + 0.00125 * u[..., 0], s[..., 1] + 0.05 * u[..., 0]], axis=-1)
+
+    class DI(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_; ref_ = self.setReference(2); Nh = cfg.getHorizon()
+            for k in range(Nh):
+                self.addVectorCost([10.0, 1.0] if k < Nh - 1 else [400.0, 40.0], cfg.getVariable(k, "state") - ref_)
+                self.addVectorCost([0.1], cfg.getVariable(k, "input"))
+            for k in range(Nh - 1):
+                self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(F, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+
+    frame = np.concatenate([rng.uniform(-1, 1, (8, 2)), np.zeros((8, 1))], axis=1); refv = np.zeros((8, 2)); res = {}
+    for flag in ("false", "true"):
+        ocp = DI(yaml.safe_load(text % flag), batch=8); ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert ocp.model_.varying_weights and ocp.model_.Qk[-1, 0] == 400.0
+        res[flag] = ocp.computeOptimalTrajectory(frame, refv)
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())

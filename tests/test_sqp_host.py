@@ -101,3 +101,32 @@ def test_warm_start_and_rho_carry_over(built):
     assert runs["warm"][1] < runs["cold"][1] and runs["warm+rho"][1] <= runs["warm"][1]
     for key in ("warm", "warm+rho"):
         assert np.abs(runs[key][0]["f"] - runs["cold"][0]["f"]).max() <= 2e-2 * np.abs(runs["cold"][0]["f"]).max()
+
+
+def test_per_frame_weights_host_formulation():
+    """terminal costs / ramps: Q, R given per frame [N, nx], [N, nu]; gradient and Hessian of the stage cost against central
+    differences of the objective in the augmented variables w = [p; x]"""
+    N = 6
+    rng = np.random.default_rng(0)
+    Qk = rng.uniform(0.1, 5.0, (N, 4)); Rk = rng.uniform(0.01, 1.0, (N, 1)); Qk[-1] *= 20.0        # heavy terminal weight
+    class CP(models.CartPole):
+        def __init__(self): models.StageOCP.__init__(self, N, 0.02, Qk, Rk)
+    mdl = CP()
+    assert mdl.varying_weights
+    B = 2
+    x = rng.normal(0, 0.5, (B, mdl.nvar)); p = rng.normal(0, 0.3, (B, 4))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    P, _ = ls.dense(0)
+    f = lambda w: mdl.objective(w[None, :4], w[None, 4:])[0]
+    w0 = np.concatenate([p[0], x[0]]); n = len(w0); h = 1e-5
+    g = np.array([(f(w0 + h * np.eye(n)[i]) - f(w0 - h * np.eye(n)[i])) / (2 * h) for i in range(n)])
+    assert np.abs(g - ls.q[0]).max() < 1e-6 * (1 + np.abs(g).max())
+    H = np.zeros((n, n))
+    for i in range(n):
+        e = h * np.eye(n)[i]
+        qp_ = mdl.local_system((w0 + e)[None, :4], (w0 + e)[None, 4:], lbx[:1], ubx[:1], lbg[:1], ubg[:1]).q[0]
+        qm_ = mdl.local_system((w0 - e)[None, :4], (w0 - e)[None, 4:], lbx[:1], ubx[:1], lbg[:1], ubg[:1]).q[0]
+        H[:, i] = (qp_ - qm_) / (2 * h)
+    assert np.abs(H - P).max() < 1e-5 * (1 + np.abs(P).max())
+    assert P[4 + (N - 1) * 5, 4 + (N - 1) * 5] == 2.0 * Qk[-1, 0]
