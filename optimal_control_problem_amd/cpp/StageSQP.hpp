@@ -48,6 +48,12 @@ class StageSQP {
   int n() const { return dims_[3]; } int m() const { return dims_[4]; } int nnzP() const { return dims_[5]; }
   int nnzA() const { return dims_[6]; } int nvar() const { return dims_[7]; } int ng() const { return m() - n(); }
 
+  // per-frame diagonal weights (terminal costs): Qk [horizon * nx], Rk [horizon * nu]
+  void setWeights(const std::vector<double> &Qk, const std::vector<double> &Rk) {
+    need(Qk.size(), (size_t)(nvar() / (nx() + nu())) * nx(), "Qk"); need(Rk.size(), (size_t)(nvar() / (nx() + nu())) * nu(), "Rk");
+    check(mpcqp_stage_set_weights(ocp_, Qk.data(), Rk.data()), "mpcqp_stage_set_weights");
+  }
+
   void setInitialGuess(const std::vector<double> &x) {            // extension: the reference always starts from zero
     need(x.size(), (size_t)batch_ * nvar(), "x");
     hip(hipMemcpy(x_, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice));

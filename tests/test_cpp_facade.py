@@ -40,3 +40,27 @@ def test_cpp_stage_sqp_on_gpu(built):
     r = subprocess.run([SQP_EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "max dynamics violation" in r.stdout
+
+
+OCP_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "ocp_cpp_test")
+
+
+def test_cpp_ocp_config_and_errors(built):
+    """OptimalControlProblem.hpp without a GPU: YAML subset reader, OCPConfig semantics, validateConfig, error behaviour"""
+    r = subprocess.run([OCP_EXE, "config"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "config ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_cpp_ocp_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; see the gpu-marked test")
+    r = subprocess.run([OCP_EXE, "run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_ocp_on_gpu(built):
+    """a C++ subclass written like the reference's examples (deployConstraintsAndAddCost / genSolver / computeOptimalTrajectory)"""
+    r = subprocess.run([OCP_EXE, "run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "run ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
