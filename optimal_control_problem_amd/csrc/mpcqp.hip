@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(WAVE) mpcqp_admm_kernel(const DevPlan pl, cons
 #define TS_STORE(ptr)
 #endif
 struct DevRes {
-  int nphase, ntemp;
+  int nphase, ntemp, nconst, rext;   // nconst constant blocks behind the factor blocks (slot nblk = -I), rext partial-sum doubles behind the solve vector
   const int *lv_ptr, *lv_diag, *lw_ptr, *lw_slot, *lw_g, *lu_ptr, *lu_dst, *lu_tmp, *lu_b, *g_ptr, *g_seg;
   int n_seg, nlev; long stage;
 };
@@ -1011,6 +1011,10 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
   }
   for (int a = wid; a < nprev; a += NW)   // (the last level has no off-diagonal block; kept for generality)
     reinterpret_cast<d4 *>(cx.BL + (long)rs.lw_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+  if (rs.nconst) {   // the constant block -I that folds the partial sums of a split run into their destination
+    double *ni = cx.BL + (long)pl.nblk * BLK;
+    for (int e = tid; e < BLK; e += NT) ni[e] = (e / BS == e % BS) ? -1.0 : 0.0;
+  }
   for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
   bsync<NW>();
 #ifdef MPCQP_TIMING
@@ -1166,11 +1170,12 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
   double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
   if (GB) { cx.BL = ws + pl.o_Lf; cx.TMP = lds; }
-  else { cx.BL = lds; cx.TMP = cx.BL + (long)pl.nblk * BLK; }
+  else { cx.BL = lds; cx.TMP = cx.BL + ((long)pl.nblk + rs.nconst) * BLK; }
   cx.X = lds + rs.stage; cx.Q = cx.X + pl.npad; cx.R = cx.Q + pl.npad;
+  double *rend = cx.R + pl.npad + rs.rext;      // the solve vector is followed by the per-wave partial sums of split runs
   if (GB && ZYG) {   // z and y are only ever indexed by their own row: in the slab they cost two coalesced streams per iteration and
-    cx.Z = ws + pl.o_Zg; cx.Y = ws + pl.o_Yg; cx.W = cx.R + pl.npad;   // free 2 * mpad doubles of LDS (one more workgroup per CU for long horizons)
-  } else { cx.Z = cx.R + pl.npad; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad; }
+    cx.Z = ws + pl.o_Zg; cx.Y = ws + pl.o_Yg; cx.W = rend;   // free 2 * mpad doubles of LDS (one more workgroup per CU for long horizons)
+  } else { cx.Z = rend; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad; }
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
@@ -1216,7 +1221,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
     if (!GB) {   // the factor blocks come back from the slab
       const double *src = ws + pl.o_Lf;
-      for (long e = tid; e < (long)pl.nblk * BLK; e += NT) lds[e] = src[e];
+      for (long e = tid; e < ((long)pl.nblk + rs.nconst) * BLK; e += NT) lds[e] = src[e];
     }
     bsync<NW>();
   } else {
@@ -1311,6 +1316,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
       ell_rows_w<NW, EU>(pl.At, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
 #ifdef MPCQP_TIMING
@@ -1390,7 +1396,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   }
   if (!GB && io.keep) {   // resident variants: park the factor in the slab for a following mpcqp_update_vectors solve
     double *dst = ws + pl.o_Lf;
-    for (long e = tid; e < (long)pl.nblk * BLK; e += NT) dst[e] = lds[e];
+    for (long e = tid; e < ((long)pl.nblk + rs.nconst) * BLK; e += NT) dst[e] = lds[e];
   }
   if (tid == 0) {
     io.status[b] = status; io.iters[b] = iter_done;
@@ -1610,13 +1616,13 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       else if (small_ok && l1 <= 40 * 1024) want = 1;
       else {
         if (small_ok && l4 <= 80 * 1024) want = 4;
-        else if (small_ok && lds_bytes_res_gb(p4, r4, !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
+        else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
         else want = 0;
       }
     }
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
-      h->rplan = build_res_plan(pl, want);
+      h->rplan = build_res_plan(pl, want, h->gblocks);
       long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
       if (h->gblocks && !getenv("MPCQP_NO_ZYG")) {
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
@@ -1652,7 +1658,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   UP(upload(h, pl.asm_b, &dp.asm_b)); UP(upload(h, pl.asm_pidx, &dp.asm_pidx)); UP(upload(h, pl.blk_diag, &dp.blk_diag));
   if (h->variant > 0) {
     const ResPlan &rp = h->rplan; DevRes &dr = h->dres;
-    dr.nphase = rp.nphase; dr.ntemp = rp.ntemp;
+    dr.nphase = rp.nphase; dr.ntemp = rp.ntemp; dr.nconst = rp.nconst; dr.rext = rp.rext;
     dr.nlev = rp.nlev;
     UP(upload(h, rp.lv_ptr, &dr.lv_ptr)); UP(upload(h, rp.lv_diag, &dr.lv_diag)); UP(upload(h, rp.lw_ptr, &dr.lw_ptr));
     UP(upload(h, rp.lw_slot, &dr.lw_slot)); UP(upload(h, rp.lw_g, &dr.lw_g)); UP(upload(h, rp.lu_ptr, &dr.lu_ptr));

@@ -102,6 +102,9 @@ enum { SOP_SUB = 0, SOP_SUBT = 1, SOP_SET = 2 };
 inline int pack_sop(int kind, int slot, int src, int dst) { return kind | (slot << 2) | (src << 14) | (dst << 23); }
 struct ResPlan {
   int nw = 1, ntemp = 0, nphase = 0;
+  // split accumulation runs: nconst constant blocks follow the nblk factor blocks (slot nblk = -I), rext doubles follow the npad
+  // entries of the solve vector (per-wave partial sums, zeroed before every solve)
+  int nconst = 0, rext = 0;
   // factorisation, per block column K
   std::vector<int> col_diag;             // [nb]
   std::vector<int> w_ptr, w_slot;        // W_IK = S_IK G_K -> temp tile (index within column)
@@ -377,13 +380,14 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
 
 // workspace layout per QP, in doubles; every section starts on a 16-double (128 B) boundary
 struct WsLayout {
-  long ellA, ellAt, ellP, Lf, Lb, T, l, u, D, E, dx, dy, Zg, Yg, stride;
+  long ellA = 0, ellAt = 0, ellP = 0, Lf = 0, Lb = 0, T = 0, l = 0, u = 0, D = 0, E = 0, dx = 0, dy = 0, Zg = 0, Yg = 0, stride = 0;
 };
 inline WsLayout ws_layout(const Plan &pl) {
   WsLayout w; long o = 0;
   auto take = [&](long cnt) { long r = o; o += (cnt + 15) / 16 * 16; return r; };
   w.ellA = take(pl.A.entries()); w.ellAt = take(pl.At.entries()); w.ellP = take(pl.P.entries());
-  w.Lf = take((long)pl.nblk * BLK); w.Lb = take((long)pl.nblk * BLK); w.T = take((long)std::max(pl.nT, 1) * BLK);
+  w.Lf = take(((long)pl.nblk + 1) * BLK);   // + the constant -I block of split runs
+  w.Lb = take((long)pl.nblk * BLK); w.T = take((long)std::max(pl.nT, 1) * BLK);
   w.l = take(pl.mpad); w.u = take(pl.mpad); w.D = take(pl.npad); w.E = take(pl.mpad);
   w.dx = take(pl.npad); w.dy = take(pl.mpad);
   w.Zg = take(pl.mpad); w.Yg = take(pl.mpad);   // z, y of the kernels that keep them out of LDS (row-indexed only, like l and u)
@@ -395,7 +399,9 @@ inline int block_id(const Plan &pl, int I, int J) {
   return -1;
 }
 
-inline ResPlan build_res_plan(const Plan &pl, int nw) {
+// split_runs: split long single-destination accumulation runs of the forward sweep over the waves (pays when the factor blocks are
+// streamed from HBM -- cart-pole N=100 -10 %, quadrotor N=50 -7 %, N=20 -2.7 % -- not when they sit in LDS)
+inline ResPlan build_res_plan(const Plan &pl, int nw, bool split_runs = false) {
   ResPlan rp; rp.nw = nw;
   const int nb = pl.nb;
   std::map<std::pair<int, int>, int> bid;
@@ -468,7 +474,7 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
   // single-op group follows the wave that produced its source block ("affinity") so that independent chains stay on
   // their own waves without synchronisation; everything else goes to the least-loaded wave.
   struct SOp { int word, src, dst; };
-  std::vector<int> owner(nb, -1);
+  std::vector<int> owner(nb + nw, -1);
   auto distribute = [&](std::vector<std::vector<SOp>> groups) {
     std::vector<std::vector<SOp>> per(nw);
     std::stable_sort(groups.begin(), groups.end(), [](const std::vector<SOp> &a, const std::vector<SOp> &b) { return a.size() > b.size(); });
@@ -493,11 +499,33 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
     return per;
   };
   std::vector<std::vector<std::vector<SOp>>> phases;
+  const int vslots = nb + nw;                       // vector blocks: nb of the solve vector + one partial-sum slot per wave
   for (int lev = nlev - 1; lev >= 0; lev--) {       // forward: t_I -= W_IJ t_J, grouped by dst I
     std::map<int, std::vector<SOp>> g;
     for (auto &o : ops) if (o.lev == lev) g[o.I].push_back({pack_sop(SOP_SUB, o.slot, o.J, o.I), o.J, o.I});
     std::vector<std::vector<SOp>> gs; for (auto &kv : g) gs.push_back(kv.second);
+    // A destination that collects many contributions (the arrow block: one op per stage) would be one long run on one wave
+    // while the others wait.  Split it: wave 0's share accumulates into the destination itself, the other shares into
+    // per-wave partial-sum slots behind the solve vector (zero at the start of every solve, so they end up holding
+    // -sum W t), and a combine phase adds them with the constant block -I:  t_I -= (-I) * partial.
+    std::vector<SOp> combine;
+    if (split_runs && nw > 1 && gs.size() == 1 && (int)gs[0].size() >= 4 * nw && vslots <= 511 && rp.rext == 0) {
+      std::vector<SOp> big = gs[0]; gs.clear();
+      const int I = big[0].dst, per = ((int)big.size() + nw - 1) / nw;
+      for (int w = 0; w < nw; w++) {
+        std::vector<SOp> part;
+        for (int q = w * per; q < std::min((int)big.size(), (w + 1) * per); q++) {
+          SOp o = big[q];
+          if (w > 0) { unsigned wd = (unsigned)o.word; o.dst = nb + w; o.word = (int)((wd & 0x7fffffu) | ((unsigned)o.dst << 23)); }
+          part.push_back(o);
+        }
+        if (!part.empty()) gs.push_back(part);
+        if (w > 0 && !part.empty()) combine.push_back({pack_sop(SOP_SUB, pl.nblk, nb + w, I), nb + w, I});
+      }
+      rp.nconst = 1; rp.rext = nw * BS;
+    }
     phases.push_back(distribute(gs));
+    if (!combine.empty()) phases.push_back(distribute({combine}));
   }
   {
     std::vector<std::vector<SOp>> gs;
@@ -516,7 +544,7 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
   rp.s_ptr.push_back(0);
   // a workgroup barrier is needed before a phase iff one of its ops touches a vector block that another wave has
   // written (RAW / WAW) or read-then-it-writes (WAR) since the last barrier
-  std::vector<int> wby(nb, -1), rby(nb, 0);
+  std::vector<int> wby(nb + nw, -1), rby(nb + nw, 0);
   rp.s_bar.assign(rp.nphase, 0);
   for (int p = 0; p < rp.nphase; p++) {
     bool conflict = false;
@@ -614,7 +642,7 @@ inline ResPlan build_res_plan(const Plan &pl, int nw) {
 // doubles of the LDS region that holds the factor blocks + temp tiles during the solve and, before the first
 // factorisation, the staged ELL values of A, A', P
 inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
-  const long blocks = ((long)pl.nblk + rp.ntemp) * BLK, ell = pl.A.entries() + pl.At.entries() + pl.P.entries();
+  const long blocks = ((long)pl.nblk + rp.nconst + rp.ntemp) * BLK, ell = pl.A.entries() + pl.At.entries() + pl.P.entries();
   return (std::max(blocks, ell) + 15) / 16 * 16;
 }
 // the same kernels with the factor blocks left in the HBM slab: LDS holds temp tiles + vectors + schedule only
@@ -622,11 +650,11 @@ inline long res_stage_doubles_gb(const ResPlan &rp) { return ((long)rp.ntemp * B
 // zy_global: z and y live in the slab as well (they are only ever indexed by their own row, so wave accesses are contiguous)
 inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp, bool zy_global = false) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;
-  return (res_stage_doubles_gb(rp) + 3L * pl.npad + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles_gb(rp) + 3L * pl.npad + rp.rext + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
 }
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
-  return (res_stage_doubles(pl, rp) + 3L * pl.npad + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles(pl, rp) + 3L * pl.npad + rp.rext + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {

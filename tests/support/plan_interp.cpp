@@ -166,11 +166,13 @@ extern "C" {
 int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw,
                      const double *Pval, const double *Aval, const double *rho, double sigma,
                      const double *rhs, double *sol, long *info) {
+  const bool split = nw >= 10000;                 // + 10000: split long accumulation runs (what the global-block kernels use)
+  nw %= 10000;
   const int force = nw >= 100 ? nw / 100 : -1;
   nw %= 100;
   Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force);
   if (!pl.error.empty()) return 1;
-  ResPlan rp = build_res_plan(pl, nw);
+  ResPlan rp = build_res_plan(pl, nw, split);
   if (info) { info[0] = rp.ntemp + 100 * pl.ordering; info[1] = rp.nphase; info[2] = lds_bytes_res(pl, rp); int nb = 0; for (int b : rp.s_bar) nb += b; info[3] = nb; }
   // the segment compression must expand back to exactly the record list (offsets, kinds, flush and barrier points)
   for (int w = 0; w < nw; w++) {
@@ -247,12 +249,16 @@ int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, 
     for (int a = 0; a < nwk; a++) { pend_slot.push_back(rp.lw_slot[w0 + a]); pend_tmp.push_back(a); }
   }
   for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
-  std::vector<double> v(pl.npad, 0.0);
+  std::vector<double> v(pl.npad + rp.rext, 0.0);      // + the zero-initialised partial sums of split accumulation runs
   for (int j = 0; j < n; j++) v[pl.pos[j]] = rhs[j];
+  if (rp.nconst) {                                     // the constant block -I behind the factor blocks
+    S.resize(((size_t)pl.nblk + 1) * BLK, 0.0);
+    for (int e = 0; e < BLK; e++) S[(size_t)pl.nblk * BLK + e] = (e / BS == e % BS) ? -1.0 : 0.0;
+  }
   // hazard check, independent of the scheduler: since the last workgroup barrier no wave may read or overwrite a
   // vector block another wave has written, nor overwrite one another wave has read
   {
-    std::vector<int> wby(pl.nb, -1), rby(pl.nb, 0);
+    std::vector<int> wby(pl.nb + nw, -1), rby(pl.nb + nw, 0);
     for (int p = 0; p < rp.nphase; p++) {
       for (int w = 0; w < nw; w++) for (int q = rp.s_ptr[p * nw + w]; q < rp.s_ptr[p * nw + w + 1]; q++) {
         unsigned op = (unsigned)rp.s_ops[q]; int src = (op >> 14) & 0x1ff, dst = op >> 23;
@@ -277,3 +283,50 @@ int plan_execute_res(int n, int m, const int *Pp, const int *Pi, const int *Ap, 
 }
 
 }  // extern "C"
+
+// Bounds of everything the kernel will address through the solve schedule: every record and every expanded segment must stay
+// inside the block array ((nblk + nconst) blocks) and the solve vector (npad + rext doubles).  Returns 0 ok, else a code.
+extern "C" int plan_check_segments(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw_enc, long *info) {
+  const bool split = nw_enc >= 10000;
+  nw_enc %= 10000;
+  const int nw = nw_enc % 100, force = nw_enc / 100 - 1;
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force, true);
+  if (!pl.error.empty()) return 1;
+  ResPlan rp = build_res_plan(pl, nw, split);
+  const long bmax = ((long)pl.nblk + rp.nconst) * BLK * 8, vmax = ((long)pl.npad + rp.rext) * 8;
+  for (size_t i = 0; i + 3 < rp.r_rec.size(); i += 4) {
+    const int b = rp.r_rec[i], s = rp.r_rec[i + 1], d = rp.r_rec[i + 2], f = rp.r_rec[i + 3];
+    if (f & RF_NOP) continue;
+    if (b < 0 || b + BLK * 8 > bmax || s < 0 || s + BS * 8 > vmax || d < 0 || d + BS * 8 > vmax) return 2;
+  }
+  long nseg = 0;
+  for (size_t i = 0; i + 7 < rp.g_seg.size(); i += 8) {
+    const int b0 = rp.g_seg[i], s0 = rp.g_seg[i + 1], d0 = rp.g_seg[i + 2], fl = rp.g_seg[i + 3], cnt = rp.g_seg[i + 4];
+    const int db = rp.g_seg[i + 5], ds = rp.g_seg[i + 6], dd = rp.g_seg[i + 7];
+    nseg++;
+    if (fl & SG_NOP) continue;
+    for (int k = 0; k < cnt; k++) {
+      const long b = b0 + (long)k * db, s = s0 + (long)k * ds, d = (fl & SG_EACH) ? d0 + (long)k * dd : d0;
+      if (b < 0 || b + BLK * 8 > bmax || s < 0 || s + BS * 8 > vmax || d < 0 || d + BS * 8 > vmax) return 3;
+    }
+  }
+  if (info) { info[0] = nseg; info[1] = rp.nconst; info[2] = rp.rext; info[3] = (long)lds_bytes_res(pl, rp); info[4] = (long)lds_bytes_res_gb(pl, rp); }
+  return 0;
+}
+
+// The per-QP HBM slab: every region offset must be set, 16-double aligned, in increasing order and inside the stride, with room for
+// its content (a kernel that faults can reset the GPUs of a host, so the layout is checked here, on the CPU).
+extern "C" int plan_check_layout(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, force_ordering, true);
+  if (!pl.error.empty()) return 1;
+  const WsLayout w = ws_layout(pl);
+  const long off[] = {w.ellA, w.ellAt, w.ellP, w.Lf, w.Lb, w.T, w.l, w.u, w.D, w.E, w.dx, w.dy, w.Zg, w.Yg, w.stride};
+  const long need[] = {pl.A.entries(), pl.At.entries(), pl.P.entries(), ((long)pl.nblk + 1) * BLK, (long)pl.nblk * BLK, (long)std::max(pl.nT, 1) * BLK,
+                       pl.mpad, pl.mpad, pl.npad, pl.mpad, pl.npad, pl.mpad, pl.mpad, pl.mpad};
+  if (off[0] != 0) return 2;
+  for (int k = 0; k < 14; k++) {
+    if (off[k] % 16 != 0) return 3;
+    if (off[k + 1] < off[k] + need[k]) return 4 + k;
+  }
+  return 0;
+}

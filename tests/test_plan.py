@@ -126,9 +126,30 @@ def test_res_plan_twisted_ordering(built, nw):
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=20)
     base = _run_res(ls, nw)
     tw = _run_res(ls, nw + 200)
+    sp = _run_res(ls, nw + 200 + 10000)                          # the same with the arrow run split over the waves (global-block plans)
+    if nw == 4:                                                    # 20 arrow ops >= 4 * nw: split; with 8 waves the run stays whole
+        assert sp["nphase"] == tw["nphase"] + 1 and sp["barriers"] <= tw["barriers"] + 2
+    else:
+        assert sp["nphase"] == tw["nphase"]
     assert base["ordering"] == 1 and tw["ordering"] == 2
     assert tw["nphase"] <= base["nphase"] // 2 + 3
     assert abs(tw["lds"] - base["lds"]) < 6144 and tw["lds"] <= 160 * 1024    # two more temp tiles (both columns of a level)
     # stage frames that do not tile 16-blocks (cart-pole f = 5) keep the plain hubs-last order
     mdl, ls, _ = models.make_workload("cartpole", 1, N=30)
     assert _run_res(ls, nw + 200)["ordering"] == 1
+
+
+@pytest.mark.parametrize("name,N", [("double_integrator", 20), ("quadrotor", 20), ("quadrotor", 50), ("cartpole", 100)])
+def test_slab_layout_and_schedule_bounds(built, name, N):
+    """host-side guards for what the kernels will address: slab regions ordered, aligned and large enough; every schedule record
+    and expanded segment inside the block array and the solve vector (incl. the partial-sum slots of split runs)"""
+    L = C.CDLL(SO)
+    L.plan_check_layout.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int]
+    L.plan_check_segments.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
+    mdl, ls, _ = models.make_workload(name, 1, N=N)
+    for force in (-1, 0, 1, 2):
+        assert L.plan_check_layout(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), force) == 0
+        for nw in (1, 4, 8):
+            info = np.zeros(8, np.int64)
+            for split in (0, 10000):
+                assert L.plan_check_segments(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), nw + 100 * (force + 1) + split, _p(info)) == 0
