@@ -867,7 +867,7 @@ __device__ __forceinline__ double seg_run(const char *BLb, const char *vecb, int
   return acc;
 }
 template <int NW, bool GB, int PD = 6>
-__device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane, long long *trace = nullptr) {
+__device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, const int g1, const char *BLb, char *vecb, const int lane, const int ni_off, long long *trace = nullptr) {
   const int r = lane >> 2, j = lane & 3;
   const int offN = (r * BS + 4 * j) * 8, offT = ((4 * j) * BS + r) * 8, offV = 32 * j, offD = 8 * r;
   double acc = 0.0;
@@ -891,6 +891,15 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
       else if (fl & SG_T) seg_each<true, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
       else seg_each<false, false>(BLb, vecb, b0, s0, d0, cnt, db, ds, dd, offN, offT, offV, offD, j, acc);
       acc = 0.0;
+    } else if (GB && b0 == ni_off && db == 0 && (fl & SG_END)) {
+      // the combine run of a split accumulation: every op is (-I) * partial, so the run is a plain vector sum -- the constant
+      // block is not fetched from the slab
+      if (j == 0) {
+        double a = 0.0;
+        for (int k = 0; k < cnt; k++) a += *reinterpret_cast<const double *>(vecb + s0 + k * ds + offD);
+        double *o = reinterpret_cast<double *>(vecb + d0 + offD); *o = *o + a;
+      }
+      wave_order();
     } else {
       acc = (fl & SG_T) ? seg_run<true, GB>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc)
                         : seg_run<false, GB>(BLb, vecb, b0, s0, cnt, db, ds, offN, offT, offV, acc);
@@ -1312,6 +1321,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   double *dxg = ws + pl.o_dx, *dyg = ws + pl.o_dy;
   int can_check = 0;
   const int sq0 = lptr[wid], sq1 = lptr[wid + 1];
+  const int ni_off = rs.nconst ? pl.nblk * BLK * 8 : -1;      // byte offset of the constant -I block (split accumulation runs)
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
@@ -1322,10 +1332,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
 #ifdef MPCQP_TIMING
       long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
       if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
-      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, trace);
+      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off, trace);
       if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
 #else
-      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane);
+      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off);
 #endif
       if (NW == 1) bsync<NW>();
       TS(5);
