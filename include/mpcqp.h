@@ -205,12 +205,16 @@ int mpcqp_stage_create(const mpcqp_stage_desc *d, mpcqp_stage **out);
  * 602-640).  `library_path` is a shared library generated by optimal_control_problem_amd/codegen.py from a traced discrete
  * map s_{k+1} = F(s_k, u_k): a scalar-generic functor instantiated into the same evaluation kernels (hipcc, gfx950), exporting
  * mpcqp_user_abi / _dims / _eval / _merit.  d->model and d->par are ignored (constants are baked into the generated code);
- * nx <= 16, nu <= 8. */
+ * nx <= 16, nu <= 8.  A library generated with a stage cost l(s, u, r) (and optionally a terminal one) -- the general form of the
+ * SX cost terms the reference sums in addScalarCost, src/OptimalControlProblem.cpp:491-497 -- also exports mpcqp_user_cost: the
+ * objective is then sum_k l(s_k, u_k, p) with its exact Hessian (the reference's hessian(f, w), SQPOptimizationSolver.cpp:55-60) in
+ * the structure the generated code reports (mpcqp_stage_pattern), and d->Q, d->R, mpcqp_stage_set_weights do not apply. */
 int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path, mpcqp_stage **out);
 void mpcqp_stage_destroy(mpcqp_stage *s);
 /* Per-frame diagonal weights (terminal costs, ramps): Qk [horizon * nx], Rk [horizon * nu], host pointers, copied; frame k is
  * weighted by Qk[k*nx ...], Rk[k*nu ...] instead of desc.Q, desc.R (the reference calls addVectorCost once per step, so weights may
- * differ by step, reference readme.md:121-128).  NULL, NULL returns to desc.Q, desc.R. */
+ * differ by step, reference readme.md:121-128).  NULL, NULL returns to desc.Q, desc.R.  MPCQP_ERR_ARG for an evaluator generated
+ * with its own stage cost. */
 int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk);
 /* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
 int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);

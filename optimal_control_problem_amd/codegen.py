@@ -94,6 +94,109 @@ class Tape:
                 stack += [nd[1], nd[2]]
         return sorted(need)
 
+    # -- simplifying constructors used by the symbolic differentiation (x + 0, x * 1, x * 0 ... fold away, so that a
+    #    structurally zero derivative is the constant 0 and the Hessian's sparsity can be read off the tape)
+    def _cv(self, i):
+        return self.nodes[i][1] if self.is_const(i) else None
+
+    def s_add(self, a, b):
+        if self._cv(a) == 0.0: return b
+        if self._cv(b) == 0.0: return a
+        return self.binary("add", a, b)
+
+    def s_sub(self, a, b):
+        if self._cv(b) == 0.0: return a
+        if self._cv(a) == 0.0: return self.s_neg(b)
+        return self.binary("sub", a, b)
+
+    def s_mul(self, a, b):
+        for x, y in ((a, b), (b, a)):
+            if self._cv(x) == 0.0: return self.const(0.0)
+            if self._cv(x) == 1.0: return y
+            if self._cv(x) == -1.0: return self.s_neg(y)
+        return self.binary("mul", a, b)
+
+    def s_div(self, a, b):
+        if self._cv(a) == 0.0: return self.const(0.0)
+        if self._cv(b) == 1.0: return a
+        return self.binary("div", a, b)
+
+    def s_neg(self, a):
+        if self.nodes[a][0] == "neg": return self.nodes[a][1]
+        return self.unary("neg", a)
+
+    def partials(self, i):
+        """[(argument, d node_i / d argument)] of node i as node ids (new nodes are appended)"""
+        nd = self.nodes[i]; k = nd[0]
+        one = self.const(1.0)
+        if k in ("in", "const"): return []
+        if k == "add": return [(nd[1], one), (nd[2], one)]
+        if k == "sub": return [(nd[1], one), (nd[2], self.const(-1.0))]
+        if k == "mul": return [(nd[1], nd[2]), (nd[2], nd[1])]
+        if k == "div": return [(nd[1], self.s_div(one, nd[2])), (nd[2], self.s_neg(self.s_div(i, nd[2])))]
+        a = nd[1]
+        if k == "neg": return [(a, self.const(-1.0))]
+        if k == "sin": return [(a, self.unary("cos", a))]
+        if k == "cos": return [(a, self.s_neg(self.unary("sin", a)))]
+        if k == "tan": return [(a, self.s_add(one, self.s_mul(i, i)))]
+        if k == "exp": return [(a, i)]
+        if k == "log": return [(a, self.s_div(one, a))]
+        if k == "sqrt": return [(a, self.s_div(self.const(0.5), i))]
+        if k == "tanh": return [(a, self.s_sub(one, self.s_mul(i, i)))]
+        raise ValueError("no derivative rule for %s" % k)
+
+    def clone(self):
+        t = Tape(self.n_in)
+        t.nodes = list(self.nodes); t._memo = dict(self._memo); t.outputs = list(self.outputs)
+        for a in ("nx", "nu", "nr"):
+            if hasattr(self, a): setattr(t, a, getattr(self, a))
+        return t
+
+
+def gradient_tape(tape):
+    """reverse-mode sweep over the SSA tape of a scalar function: a new tape whose outputs are d out / d input_k, k < n_in"""
+    g = tape.clone()
+    (out,) = tape.outputs
+    zero = g.const(0.0)
+    bar = {out: g.const(1.0)}
+    for i in sorted(tape.live_nodes(), reverse=True):
+        if i not in bar or g.nodes[i][0] in ("in", "const"):
+            continue
+        for a, d in g.partials(i):
+            bar[a] = g.s_add(bar.get(a, zero), g.s_mul(bar[i], d))
+    g.outputs = [bar.get(k, zero) for k in range(tape.n_in)]
+    return g
+
+
+def tangent_outputs(tape, k):
+    """forward-mode sweep in direction input k (symbolic): node ids of d outputs / d input_k, appended to a scratch clone"""
+    t = tape.clone()
+    zero, one = t.const(0.0), t.const(1.0)
+    dot = {}
+    for i in tape.live_nodes():
+        nd = t.nodes[i]
+        if nd[0] == "in":
+            dot[i] = one if nd[1] == k else zero
+        elif nd[0] == "const":
+            dot[i] = zero
+        else:
+            acc = zero
+            for a, d in t.partials(i):
+                acc = t.s_add(acc, t.s_mul(dot[a], d))
+            dot[i] = acc
+    return t, [dot[o] for o in tape.outputs]
+
+
+def hessian_mask(gtape):
+    """structural sparsity [n_in, n_in] of the Hessian whose gradient tape is gtape (entries that are not identically zero)"""
+    n = gtape.n_in
+    mask = np.zeros((n, n), bool)
+    for k in range(n):
+        t, d = tangent_outputs(gtape, k)
+        for r in range(n):
+            mask[r, k] = not (t.is_const(d[r]) and t.nodes[d[r]][1] == 0.0)
+    return mask | mask.T
+
 
 class TS:
     """scalar tracer"""
@@ -291,9 +394,28 @@ def _trace_fn(fn, nx, nu, n_out, what):
     return tape
 
 
-def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None):
+def trace_cost(lfun, nx, nu, nr):
+    """stage cost l(s, u, r) -> scalar on tracers; returns (value tape, gradient tape) over inputs [s; u; r]"""
+    tape = Tape(nx + nu + nr)
+    mk = lambda a, b: TV(tape, [TS(tape, i) for i in range(a, b)])
+    out = lfun(mk(0, nx), mk(nx, nx + nu), mk(nx + nu, nx + nu + nr))
+    if isinstance(out, TV) and len(out) == 1:
+        out = out.items[0]
+    if isinstance(out, (int, float, np.integer, np.floating)):
+        out = TS._lift(tape, out)
+    if not isinstance(out, TS):
+        raise ValueError("the stage cost must return one scalar")
+    tape.outputs = [out.idx]
+    tape.nx, tape.nu, tape.nr = nx, nu, nr
+    return tape, gradient_tape(tape)
+
+
+def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None):
     """Run F (and the optional per-stage path constraint hfun) once on tracers.  F(s, u) -> s_next with s [..., nx],
-    u [..., nu] (the contract of models.StageOCP.F); hfun(s, u) -> [..., nh] with bounds h_lo <= hfun <= h_hi."""
+    u [..., nu] (the contract of models.StageOCP.F); hfun(s, u) -> [..., nh] with bounds h_lo <= hfun <= h_hi.
+    lcost(s, u, r) -> scalar: a general stage cost summed over the frames (r = the reference parameter, size nx), replacing
+    the diagonal tracking weights; lterm: the same for the last frame only (terminal cost).  Their gradients are derived
+    on the tape (reverse mode); the kernels differentiate those once more with dual numbers for the exact Hessian."""
     tape = _trace_fn(F, nx, nu, nx, "F must return the next state")
     tape.nh = int(nh) if hfun is not None else 0
     tape.path = None
@@ -301,6 +423,18 @@ def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None):
         tape.path = _trace_fn(hfun, nx, nu, tape.nh, "hfun must return the path-constraint values")
         tape.h_lo = [float(v) for v in np.broadcast_to(np.asarray(h_lo, float), (tape.nh,))]
         tape.h_hi = [float(v) for v in np.broadcast_to(np.asarray(h_hi, float), (tape.nh,))]
+    tape.cost = None
+    if lcost is not None:
+        L, G = trace_cost(lcost, nx, nu, nx)
+        mask = hessian_mask(G)
+        LT = GT = None
+        if lterm is not None:
+            LT, GT = trace_cost(lterm, nx, nu, nx)
+            mask = mask | hessian_mask(GT)
+        mask = mask | np.eye(mask.shape[0], dtype=bool)      # keep the diagonal in the pattern
+        tape.cost = dict(L=L, G=G, LT=LT, GT=GT, mask=mask)
+    elif lterm is not None:
+        raise ValueError("a terminal cost needs a stage cost")
     return tape
 
 
@@ -319,7 +453,8 @@ def _emit_body(tape):
     for i in live:
         nd = tape.nodes[i]
         if nd[0] == "in":
-            ref[i] = "s[%d]" % nd[1] if nd[1] < nx else "u[%d]" % (nd[1] - nx)
+            nu = getattr(tape, "nu", tape.n_in - nx)
+            ref[i] = "s[%d]" % nd[1] if nd[1] < nx else "u[%d]" % (nd[1] - nx) if nd[1] < nx + nu else "r[%d]" % (nd[1] - nx - nu)
         elif nd[0] == "const":
             ref[i] = _lit(nd[1])
         elif nd[0] in _UNARY:
@@ -341,13 +476,22 @@ def _blit(v):
 def emit_functor(tape, name="SmUser"):
     """C++ source of the functor (same shape as the zoo's functors in csrc/stage_models.hpp)"""
     nh = getattr(tape, "nh", 0)
+    cost = getattr(tape, "cost", None)
     hbody = _emit_body(tape.path) if nh else ""
-    src = ("struct %s {\n  static constexpr int nx = %d, nu = %d, nh = %d;\n"
+    src = ("struct %s {\n  static constexpr int nx = %d, nu = %d, nh = %d, has_cost = %d, has_term = %d;\n"
            "  template <class T> SM_HD static void F(const double *, double, const T *s, const T *u, T *out) {\n%s\n  }\n"
-           "  template <class T> SM_HD static void H(const T *s, const T *u, T *out) {\n%s\n  }\n};\n" % (name, tape.nx, tape.nu, nh, _emit_body(tape), hbody))
+           "  template <class T> SM_HD static void H(const T *s, const T *u, T *out) {\n%s\n  }\n"
+           % (name, tape.nx, tape.nu, nh, 1 if cost else 0, 1 if cost and cost["LT"] is not None else 0, _emit_body(tape), hbody))
+    if cost:
+        # L: out[0] = l(s, u, r); LG: out[nx + nu + nx] = dl / d[s; u; r]; LT, LTG: the terminal frame's
+        for fn, tp in (("L", cost["L"]), ("LG", cost["G"]), ("LT", cost["LT"] or cost["L"]), ("LTG", cost["GT"] or cost["G"])):
+            src += "  template <class T> SM_HD static void %s(const T *s, const T *u, const T *r, T *out) {\n%s\n  }\n" % (fn, _emit_body(tp))
+    src += "};\n"
     lo = ", ".join(_blit(v) for v in tape.h_lo) if nh else "0.0"
     hi = ", ".join(_blit(v) for v in tape.h_hi) if nh else "0.0"
     src += "static const double %s_h_lo[] = {%s};\nstatic const double %s_h_hi[] = {%s};\n" % (name, lo, name, hi)
+    mk = ", ".join(str(int(v)) for v in cost["mask"].ravel()) if cost else "0"
+    src += "static const unsigned char %s_cost_mask[] = {%s};\n" % (name, mk)
     return src
 
 
@@ -360,6 +504,13 @@ int mpcqp_user_abi() { return STAGE_ABI_VERSION; }
 void mpcqp_user_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
 int mpcqp_user_nh() { return SmUser::nh; }
 void mpcqp_user_path_bounds(double *lo, double *hi) { for (int i = 0; i < SmUser::nh; i++) { lo[i] = SmUser_h_lo[i]; hi[i] = SmUser_h_hi[i]; } }
+// general stage cost: 1 and the Hessian's structure over [s; u; r] (row-major (f + nx)^2 bytes), or 0 for diagonal tracking weights
+int mpcqp_user_cost(unsigned char *mask) {
+  if (!SmUser::has_cost) return 0;
+  const int nl = 2 * SmUser::nx + SmUser::nu;
+  for (int i = 0; i < nl * nl; i++) mask[i] = SmUser_cost_mask[i];
+  return 1;
+}
 int mpcqp_user_eval(const StageDev *sd, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
                     const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, void *stream) {
   return (int)stage_launch_eval<SmUser>(*sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u, (hipStream_t)stream);
@@ -375,6 +526,23 @@ _HOST_TMPL = '''// generated by optimal_control_problem_amd/codegen.py -- host b
 #include "stage_models.hpp"
 
 %(functor)s
+// val [1], grad [nl], hess [nl * nl] row-major over [s; u; r], nl = 2 nx + nu; term != 0: the terminal frame's cost
+template <class M> static void host_cost(const double *s, const double *u, const double *r, int term, double *val, double *grad, double *hess) {
+  if constexpr (M::has_cost != 0) {
+    constexpr int nx = M::nx, nu = M::nu, nl = 2 * nx + nu;
+    double v[1];
+    if (term) M::template LT<double>(s, u, r, v); else M::template L<double>(s, u, r, v);
+    val[0] = v[0];
+    for (int c = 0; c < nl; c++) {
+      Dual sd[nx], ud[nu], rd[nx], gd[nl];
+      for (int i = 0; i < nx; i++) sd[i] = {s[i], i == c ? 1.0 : 0.0};
+      for (int i = 0; i < nu; i++) ud[i] = {u[i], nx + i == c ? 1.0 : 0.0};
+      for (int i = 0; i < nx; i++) rd[i] = {r[i], nx + nu + i == c ? 1.0 : 0.0};
+      if (term) M::template LTG<Dual>(sd, ud, rd, gd); else M::template LG<Dual>(sd, ud, rd, gd);
+      for (int i = 0; i < nl; i++) { hess[i * nl + c] = gd[i].d; grad[i] = gd[i].v; }
+    }
+  }
+}
 extern "C" {
 void user_host_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
 // out [nx], jac [nx * (nx + nu)] row-major: forward-mode duals, one direction per pass (what a device thread does)
@@ -389,6 +557,10 @@ void user_host_eval(const double *s, const double *u, double *out, double *jac) 
   }
 }
 int user_host_nh() { return SmUser::nh; }
+int user_host_has_cost() { return SmUser::has_cost; }
+void user_host_cost(const double *s, const double *u, const double *r, int term, double *val, double *grad, double *hess) {
+  host_cost<SmUser>(s, u, r, term, val, grad, hess);
+}
 // out [nh], jac [nh * (nx + nu)] row-major
 void user_host_path(const double *s, const double *u, double *out, double *jac) {
   constexpr int nx = SmUser::nx, nu = SmUser::nu, f = nx + nu, nh = SmUser::nh;

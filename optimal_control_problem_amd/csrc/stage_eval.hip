@@ -29,9 +29,11 @@ struct mpcqp_stage {
   std::vector<int> Pp, Pi, Ap, Ai;
   int *dPp = nullptr, *dAp = nullptr;
   double *dQk = nullptr, *dRk = nullptr;
+  unsigned char *dmask = nullptr;     // Hessian structure of a generated general stage cost
   void *user_lib = nullptr;           // dlopen handle of a generated dynamics library (model == MPCQP_MODEL_USER)
   user_eval_fn user_eval = nullptr;
   user_merit_fn user_merit = nullptr;
+  bool general_cost = false;          // the library carries its own stage cost: Q, R and mpcqp_stage_set_weights do not apply
 };
 
 __global__ void __launch_bounds__(256) stage_step_kernel(int batch, int nvar, int n, int np, double alpha, const double *__restrict__ dw,
@@ -84,7 +86,8 @@ int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d) {
   return MPCQP_OK;
 }
 
-static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh, const double *h_lo, const double *h_hi, mpcqp_stage *s) {
+static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh, const double *h_lo, const double *h_hi, mpcqp_stage *s,
+                               const unsigned char *cost_mask = nullptr) {
   int dev = 0;
   if (int rc = mpcqp_pick_device(d->device, &dev)) return rc;
   s->desc = *d; s->device = dev;
@@ -97,6 +100,7 @@ static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh
   for (int i = 0; i < SM_MAXNU; i++) sd.R[i] = d->R[i];
   for (int i = 0; i < SM_NPAR; i++) sd.par[i] = d->par[i];
   sm_build_pattern(sd.nx, sd.nu, sd.N, sd.nh, s->Pp, s->Pi, s->Ap, s->Ai);
+  if (cost_mask) sm_build_cost_pattern(sd.nx, sd.nu, sd.N, cost_mask, s->Pp, s->Pi);
   sd.nnzP = (int)s->Pi.size(); sd.nnzA = (int)s->Ai.size();
   if (hipSetDevice(dev) != hipSuccess) return mpcqp_set_error(MPCQP_ERR_HIP, "hipSetDevice failed");
   const size_t bytes = (size_t)(sd.n + 1) * sizeof(int);
@@ -105,7 +109,13 @@ static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh
   if (hipMemcpy(s->dPp, s->Pp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->dAp, s->Ap.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
     return mpcqp_set_error(MPCQP_ERR_HIP, "upload of the column pointers failed");
-  sd.Pp = s->dPp; sd.Ap = s->dAp; sd.Qk = nullptr; sd.Rk = nullptr;
+  sd.Pp = s->dPp; sd.Ap = s->dAp; sd.Qk = nullptr; sd.Rk = nullptr; sd.hmask = nullptr;
+  if (cost_mask) {
+    const size_t mb = (size_t)(sd.f + sd.nx) * (sd.f + sd.nx);
+    if (hipMalloc(&s->dmask, mb) != hipSuccess || hipMemcpy(s->dmask, cost_mask, mb, hipMemcpyHostToDevice) != hipSuccess)
+      return mpcqp_set_error(MPCQP_ERR_HIP, "upload of the cost structure failed");
+    sd.hmask = s->dmask;
+  }
   return MPCQP_OK;
 }
 
@@ -149,7 +159,10 @@ int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path,
   mpcqp_stage *s = new mpcqp_stage();
   s->user_lib = lib; s->user_eval = ev; s->user_merit = me;
   mpcqp_stage_desc dd = *d; dd.model = MPCQP_MODEL_USER;
-  if (int rc = stage_create_common(&dd, nx, nu, nh, h_lo, h_hi, s)) { mpcqp_stage_destroy(s); return rc; }
+  std::vector<unsigned char> mask((size_t)(2 * nx + nu) * (2 * nx + nu));
+  auto cf = (int (*)(unsigned char *))dlsym(lib, "mpcqp_user_cost");
+  s->general_cost = cf && cf(mask.data());
+  if (int rc = stage_create_common(&dd, nx, nu, nh, h_lo, h_hi, s, s->general_cost ? mask.data() : nullptr)) { mpcqp_stage_destroy(s); return rc; }
   *out = s;
   return MPCQP_OK;
 }
@@ -161,6 +174,7 @@ void mpcqp_stage_destroy(mpcqp_stage *s) {
   if (s->dAp) (void)hipFree(s->dAp);
   if (s->dQk) (void)hipFree(s->dQk);
   if (s->dRk) (void)hipFree(s->dRk);
+  if (s->dmask) (void)hipFree(s->dmask);
   if (s->user_lib) dlclose(s->user_lib);
   delete s;
 }
@@ -168,6 +182,7 @@ void mpcqp_stage_destroy(mpcqp_stage *s) {
 int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk) {
   if (!s) return mpcqp_set_error(MPCQP_ERR_ARG, "stage handle is null");
   if ((Qk == nullptr) != (Rk == nullptr)) return mpcqp_set_error(MPCQP_ERR_ARG, "give both weight arrays or neither");
+  if (s->general_cost) return mpcqp_set_error(MPCQP_ERR_ARG, "this evaluator was generated with its own stage cost; diagonal weights do not apply");
   MPCQP_HIPCHK(hipSetDevice(s->device));
   StageDev &sd = s->sd;
   if (!Qk) { sd.Qk = nullptr; sd.Rk = nullptr; return MPCQP_OK; }

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "stage_models.hpp"
 
-#define STAGE_ABI_VERSION 3
+#define STAGE_ABI_VERSION 4
 
 struct StageDev {
   int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows
@@ -17,6 +17,7 @@ struct StageDev {
   double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
   const int *Pp, *Ap;   // device copies of the column pointers
   const double *Qk, *Rk;   // optional per-frame diagonal weights [N * nx], [N * nu] (device; NULL = Q, R for every frame)
+  const unsigned char *hmask;   // general stage cost (M::has_cost): Hessian structure over [s; u; r], (f + nx)^2 bytes (device)
 };
 
 template <class M>
@@ -34,19 +35,52 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   double *Pc = P + (long)b * sd.nnzP + sd.Pp[j], *Ac = A + (long)b * sd.nnzA + sd.Ap[j];
   double *qb = q + (long)b * n, *lb = l + (long)b * sd.m, *ub = u + (long)b * sd.m;
   if (j < nx) {
-    // column p_i: H = d2f/dp_i2 = 2 N Q_i, d2f/dp_i ds_k[i] = -2 Q_i; grad = -2 Q_i sum_k (s_k[i] - p_i); rows l = u = p - p
     const double pi = pb[j];
-    double e = 0.0;
-    if (sd.Qk) {   // per-frame weights: d2f/dp_i2 = 2 sum_k Q_k,i
-      double qs = 0.0;
+    if constexpr (M::has_cost) {
+      // general stage cost: column p_i of the Hessian = sum over the frames of d(grad l_k)/dr_i (dual numbers through the
+      // generated gradient); the rows p_r accumulate over k, the rows of frame k are written as they come
+      constexpr int nl = f + nx;
+      const unsigned char *mk = sd.hmask + f + j;
+      int e = 0;
+#pragma unroll
+      for (int r = 0; r < nx; r++) e += mk[(f + r) * nl] ? 1 : 0;
+      double acc[nx], qa = 0.0;
+#pragma unroll
+      for (int r = 0; r < nx; r++) acc[r] = 0.0;
+      Dual s[nx], uu[nu], rr[nx], g[nl];
+#pragma unroll
+      for (int i = 0; i < nx; i++) rr[i] = {pb[i], i == j ? 1.0 : 0.0};
+      for (int k = 0; k < N; k++) {
+        const double *fr = xb + k * f;
+#pragma unroll
+        for (int i = 0; i < nx; i++) s[i] = {fr[i], 0.0};
+#pragma unroll
+        for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], 0.0};
+        if (M::has_term && k == N - 1) M::template LTG<Dual>(s, uu, rr, g); else M::template LG<Dual>(s, uu, rr, g);
+        double gv = 0.0;
+#pragma unroll
+        for (int r = 0; r < nx; r++) { acc[r] += g[f + r].d; gv = r == j ? g[f + r].v : gv; }
+        qa += gv;
+#pragma unroll
+        for (int r = 0; r < f; r++) if (mk[r * nl]) Pc[e++] = g[r].d;
+      }
+      e = 0;
+#pragma unroll
+      for (int r = 0; r < nx; r++) if (mk[(f + r) * nl]) Pc[e++] = acc[r];
+      qb[j] = qa;
+    } else if (sd.Qk) {   // per-frame weights: d2f/dp_i2 = 2 sum_k Q_k,i
+      // column p_i: H = d2f/dp_i2 = 2 N Q_i, d2f/dp_i ds_k[i] = -2 Q_i; grad = -2 Q_i sum_k (s_k[i] - p_i); rows l = u = p - p
+      double e = 0.0, qs = 0.0;
       for (int k = 0; k < N; k++) { const double Qi = sd.Qk[k * nx + j]; qs += Qi; Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
       Pc[0] = 2.0 * qs;
+      qb[j] = -2.0 * e;
     } else {
+      double e = 0.0;
       const double Qi = sd.Q[j];
       Pc[0] = 2.0 * N * Qi;
       for (int k = 0; k < N; k++) { Pc[1 + k] = -2.0 * Qi; e += (xb[k * f + j] - pi) * Qi; }
+      qb[j] = -2.0 * e;
     }
-    qb[j] = -2.0 * e;
     Ac[0] = 1.0;
     lb[j] = pi - pi; ub[j] = pi - pi;
     return;
@@ -54,7 +88,27 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   const int jj = j - nx, k = jj / f, c = jj - k * f;
   const double *fr = xb + k * f;
   const double xv = fr[c];
-  if (c < nx) {
+  Dual s[nx], uu[nu];
+#pragma unroll
+  for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
+#pragma unroll
+  for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
+  if constexpr (M::has_cost) {
+    // column frame_k[c] of the Hessian of l_k: the dual parts of the generated gradient, rows p first, then the frame's
+    constexpr int nl = f + nx;
+    const unsigned char *mk = sd.hmask + c;
+    Dual rr[nx], g[nl];
+#pragma unroll
+    for (int i = 0; i < nx; i++) rr[i] = {pb[i], 0.0};
+    if (M::has_term && k == N - 1) M::template LTG<Dual>(s, uu, rr, g); else M::template LG<Dual>(s, uu, rr, g);
+    int e = 0;
+    double gv = 0.0;
+#pragma unroll
+    for (int i = 0; i < nx; i++) if (mk[(f + i) * nl]) Pc[e++] = g[f + i].d;
+#pragma unroll
+    for (int r = 0; r < f; r++) { if (mk[r * nl]) Pc[e++] = g[r].d; gv = r == c ? g[r].v : gv; }
+    qb[j] = gv;
+  } else if (c < nx) {
     const double Qc = sd.Qk ? sd.Qk[k * nx + c] : sd.Q[c];
     Pc[0] = -2.0 * Qc; Pc[1] = 2.0 * Qc;
     qb[j] = 2.0 * (xv - pb[c]) * Qc;
@@ -67,11 +121,6 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   int a = 0;
   Ac[a++] = 1.0;
   if (k >= 1 && c < nx) Ac[a++] = 1.0;
-  Dual s[nx], uu[nu];
-#pragma unroll
-  for (int i = 0; i < nx; i++) s[i] = {fr[i], i == c ? 1.0 : 0.0};
-#pragma unroll
-  for (int i = 0; i < nu; i++) uu[i] = {fr[nx + i], nx + i == c ? 1.0 : 0.0};
   if (k < N - 1) {
     Dual out[nx];
     M::template F<Dual>(sd.par, sd.dt, s, uu, out);
@@ -117,9 +166,21 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
     const double *fr = xb + k * f;
     double s[nx], uu[nu];
 #pragma unroll
-    for (int i = 0; i < nx; i++) { s[i] = fr[i]; const double e = s[i] - pb[i]; cost += e * e * (sd.Qk ? sd.Qk[k * nx + i] : sd.Q[i]); }
+    for (int i = 0; i < nx; i++) s[i] = fr[i];
 #pragma unroll
-    for (int i = 0; i < nu; i++) { uu[i] = fr[nx + i]; cost += uu[i] * uu[i] * (sd.Rk ? sd.Rk[k * nu + i] : sd.R[i]); }
+    for (int i = 0; i < nu; i++) uu[i] = fr[nx + i];
+    if constexpr (M::has_cost) {
+      double rr[nx], lv[1];
+#pragma unroll
+      for (int i = 0; i < nx; i++) rr[i] = pb[i];
+      if (M::has_term && k == sd.N - 1) M::template LT<double>(s, uu, rr, lv); else M::template L<double>(s, uu, rr, lv);
+      cost += lv[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < nx; i++) { const double e = s[i] - pb[i]; cost += e * e * (sd.Qk ? sd.Qk[k * nx + i] : sd.Q[i]); }
+#pragma unroll
+      for (int i = 0; i < nu; i++) cost += uu[i] * uu[i] * (sd.Rk ? sd.Rk[k * nu + i] : sd.R[i]);
+    }
     if (k < sd.N - 1) {
       double out[nx];
       M::template F<double>(sd.par, sd.dt, s, uu, out);

@@ -74,7 +74,7 @@ SM_HD void sm_rk4(const double *par, double h, const T *s, const T *u, T *out) {
 
 // nx = 2, nu = 1; exact zero-order-hold map (models.py DoubleIntegrator.F); no parameters
 struct SmDoubleIntegrator {
-  static constexpr int nx = 2, nu = 1, nh = 0;
+  static constexpr int nx = 2, nu = 1, nh = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void F(const double *, double h, const T *s, const T *u, T *out) {
     out[0] = s[0] + h * s[1] + ((0.5 * h) * h) * u[0];
@@ -84,7 +84,7 @@ struct SmDoubleIntegrator {
 
 // 12-state quadrotor (models.py Quadrotor.cdyn); par = {mass, grav, arm, kappa, Jx, Jy, Jz}
 struct SmQuadrotor {
-  static constexpr int nx = 12, nu = 4, nh = 0;
+  static constexpr int nx = 12, nu = 4, nh = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
     const double mass = par[0], grav = par[1], arm = par[2], kappa = par[3], Jx = par[4], Jy = par[5], Jz = par[6];
@@ -110,7 +110,7 @@ struct SmQuadrotor {
 
 // cart-pole, s = [x, theta, xdot, thetadot], theta = 0 upright (models.py CartPole.cdyn); par = {mc, mp, length, grav}
 struct SmCartPole {
-  static constexpr int nx = 4, nu = 1, nh = 0;
+  static constexpr int nx = 4, nu = 1, nh = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
     const double mc = par[0], mp = par[1], len = par[2], grav = par[3];
@@ -160,5 +160,26 @@ inline void sm_build_pattern(int nx, int nu, int N, int nh, std::vector<int> &Pp
       if (k < N - 1) for (int r = 0; r < nx; r++) Ai.push_back(n + k * nx + r);
       for (int r = 0; r < nh; r++) Ai.push_back(n + (N - 1) * nx + k * nh + r);
       Ap.push_back((int)Ai.size());
+    }
+}
+
+// P structure for a general stage cost sum_k l(s_k, u_k, p) (generated libraries, codegen.py): mask is the Hessian's structure over
+// the local variables [s; u; r] (row-major nl x nl, nl = f + nx, symmetric, diagonal set).  Both triangles, rows ascending:
+//   column p_i: rows p_r with mask[f + r][f + i], then per frame k the rows frame_k[r] with mask[r][f + i]
+//   column frame_k[c]: rows p_i with mask[f + i][c], then rows frame_k[r] with mask[r][c]
+inline void sm_build_cost_pattern(int nx, int nu, int N, const unsigned char *mask, std::vector<int> &Pp, std::vector<int> &Pi) {
+  const int f = nx + nu, np = nx, nl = f + np;
+  Pp.assign(1, 0); Pi.clear();
+  for (int i = 0; i < np; i++) {
+    for (int r = 0; r < np; r++) if (mask[(f + r) * nl + f + i]) Pi.push_back(r);
+    for (int k = 0; k < N; k++)
+      for (int r = 0; r < f; r++) if (mask[r * nl + f + i]) Pi.push_back(np + k * f + r);
+    Pp.push_back((int)Pi.size());
+  }
+  for (int k = 0; k < N; k++)
+    for (int c = 0; c < f; c++) {
+      for (int i = 0; i < np; i++) if (mask[(f + i) * nl + c]) Pi.push_back(i);
+      for (int r = 0; r < f; r++) if (mask[r * nl + c]) Pi.push_back(np + k * f + r);
+      Pp.push_back((int)Pi.size());
     }
 }

@@ -152,6 +152,12 @@ class StageOCP:
         """[..., nh] path-constraint values; must accept complex input (override together with nh, h_lo, h_hi)"""
         raise NotImplementedError
 
+    # optional general stage cost: lcost(s, u, r) -> [...] replaces the diagonal tracking terms, f = sum_k lcost(s_k, u_k, p),
+    # lterm the same for the last frame only.  Any SX expression can be a cost term in the reference (addScalarCost,
+    # src/OptimalControlProblem.cpp:491-497) and its QP uses the exact Hessian (SQPOptimizationSolver.cpp:55-60); here the
+    # callables are traced (codegen.trace_cost), the gradient is derived on the tape and the Hessian is its derivative.
+    lcost = None; lterm = None
+
     def __init__(self, N, dt, Q, R):
         self.N, self.dt = int(N), float(dt)
         # diagonal weights, the same for every frame ([nx], [nu]) or one row per frame ([N, nx], [N, nu]: terminal costs,
@@ -166,7 +172,19 @@ class StageOCP:
         self.ngd = (self.N - 1) * self.nx                 # dynamics rows
         self.ng = self.ngd + self.N * self.nh             # all general rows: dynamics, then nh path rows per frame
         self.m = self.n + self.ng
+        self.general_cost = self.lcost is not None
+        if self.general_cost:
+            from . import codegen
+            self._ltape, self._gtape = codegen.trace_cost(self.lcost, self.nx, self.nu, self.nx)
+            mask = codegen.hessian_mask(self._gtape)
+            self._lttape = self._gttape = None
+            if self.lterm is not None:
+                self._lttape, self._gttape = codegen.trace_cost(self.lterm, self.nx, self.nu, self.nx)
+                mask = mask | codegen.hessian_mask(self._gttape)
+            self.cost_mask = mask | np.eye(mask.shape[0], dtype=bool)
         self._build_pattern()
+        if self.general_cost:
+            self._build_cost_pattern()
 
     # -- structure -------------------------------------------------------------------------------
     def _build_pattern(self):
@@ -212,6 +230,56 @@ class StageOCP:
                 Ap.append(len(Ai))
         self.Ap = np.asarray(Ap, np.int32); self.Ai = np.asarray(Ai, np.int32)
 
+    def _build_cost_pattern(self):
+        """P structure of a general stage cost (csrc/stage_models.hpp sm_build_cost_pattern): both triangles, rows ascending;
+        per entry the Hessian element it takes: (frame k or -1 = summed over the frames, local row, local column)"""
+        nx, f, N, npp = self.nx, self.f, self.N, self.np
+        mk = self.cost_mask
+        Pp = [0]; Pi = []; src = []
+        for i in range(npp):
+            for r in range(npp):
+                if mk[f + r, f + i]: Pi.append(r); src.append((-1, f + r, f + i))
+            for k in range(N):
+                for r in range(f):
+                    if mk[r, f + i]: Pi.append(npp + k * f + r); src.append((k, r, f + i))
+            Pp.append(len(Pi))
+        for k in range(N):
+            for c in range(f):
+                for i in range(npp):
+                    if mk[f + i, c]: Pi.append(i); src.append((k, f + i, c))
+                for r in range(f):
+                    if mk[r, c]: Pi.append(npp + k * f + r); src.append((k, r, c))
+                Pp.append(len(Pi))
+        self.Pp = np.asarray(Pp, np.int32); self.Pi = np.asarray(Pi, np.int32)
+        self._P_src = np.asarray(src, np.int64)
+
+    def _cost_inputs(self, p, x):
+        s, u = self.frames(x)
+        r = np.broadcast_to(p[:, None, :], s.shape)
+        return [s[..., i] for i in range(self.nx)] + [u[..., i] for i in range(self.nu)] + [r[..., i] for i in range(self.nx)]
+
+    def _cost_eval(self, tape, ttape, inputs):
+        """outputs of tape on every frame [B, N], the last frame taken from ttape when there is a terminal cost"""
+        shape = np.shape(inputs[0]); dt = np.result_type(*inputs)
+        out = [np.broadcast_to(np.asarray(v), shape).astype(dt) for v in tape.evaluate(inputs)]
+        if ttape is not None:
+            for o, v in zip(out, ttape.evaluate(inputs)):
+                o[:, -1] = np.broadcast_to(np.asarray(v), shape)[:, -1]
+        return out
+
+    def cost_derivatives(self, p, x):
+        """(grad [B, N, nl], hess [B, N, nl, nl]) of the stage cost on every frame over [s; u; r]: gradient tape evaluated
+        directly, Hessian columns by complex-step differentiation of the gradient tape (exact to rounding)"""
+        inputs = self._cost_inputs(p, x)
+        nl = len(inputs); B, N = inputs[0].shape
+        grad = np.stack(self._cost_eval(self._gtape, self._gttape, inputs), axis=-1)
+        hess = np.zeros((B, N, nl, nl)); eps = 1e-30
+        for c in range(nl):
+            ins = [v.astype(complex) for v in inputs]
+            ins[c] = ins[c] + 1j * eps
+            hess[..., :, c] = np.stack(self._cost_eval(self._gtape, self._gttape, ins), axis=-1).imag / eps
+        return grad, hess
+
     # -- dynamics (override) ---------------------------------------------------------------------
     def cdyn(self, s, u):
         """continuous dynamics ds/dt, arrays [..., nx], [..., nu]; must accept complex input"""
@@ -244,6 +312,8 @@ class StageOCP:
         return X[:, :, :self.nx], X[:, :, self.nx:]
 
     def objective(self, p, x):
+        if self.general_cost:
+            return self._cost_eval(self._ltape, self._lttape, self._cost_inputs(p, x))[0].sum(axis=1)
         s, u = self.frames(x)
         e = s - p[:, None, :]
         if self.varying_weights:
@@ -277,16 +347,25 @@ class StageOCP:
         B = x.shape[0]; N, nx, nu, f, npp, n = self.N, self.nx, self.nu, self.f, self.np, self.n
         s, u = self.frames(x)
         e = s - p[:, None, :]
-        # Hessian values are constant
-        Pv = np.zeros(len(self.Pi))
-        Pv[self._P_pp] = 2.0 * self.Qk.sum(axis=0) if self.varying_weights else 2.0 * N * self.Q
-        Pv[self._P_sp] = -2.0 * self.Qk; Pv[self._P_ps] = -2.0 * self.Qk
-        Pv[self._P_ss] = 2.0 * self.Qk; Pv[self._P_uu] = 2.0 * self.Rk
-        P = np.broadcast_to(Pv, (B, len(Pv))).copy()
         q = np.zeros((B, n))
-        q[:, :npp] = -2.0 * (np.einsum("bki,ki->bi", e, self.Qk) if self.varying_weights else np.einsum("bki,i->bi", e, self.Q))
-        qf = q[:, npp:].reshape(B, N, f)
-        qf[:, :, :nx] = 2.0 * e * self.Qk; qf[:, :, nx:] = 2.0 * u * self.Rk
+        if self.general_cost:
+            grad, hess = self.cost_derivatives(p, x)
+            src = self._P_src; summed = src[:, 0] < 0
+            P = np.zeros((B, len(self.Pi)))
+            P[:, summed] = hess[:, :, src[summed, 1], src[summed, 2]].sum(axis=1)
+            P[:, ~summed] = hess[:, src[~summed, 0], src[~summed, 1], src[~summed, 2]]
+            q[:, :npp] = grad[:, :, f:].sum(axis=1)
+            q[:, npp:] = grad[:, :, :f].reshape(B, -1)
+        else:
+            # Hessian values are constant
+            Pv = np.zeros(len(self.Pi))
+            Pv[self._P_pp] = 2.0 * self.Qk.sum(axis=0) if self.varying_weights else 2.0 * N * self.Q
+            Pv[self._P_sp] = -2.0 * self.Qk; Pv[self._P_ps] = -2.0 * self.Qk
+            Pv[self._P_ss] = 2.0 * self.Qk; Pv[self._P_uu] = 2.0 * self.Rk
+            P = np.broadcast_to(Pv, (B, len(Pv))).copy()
+            q[:, :npp] = -2.0 * (np.einsum("bki,ki->bi", e, self.Qk) if self.varying_weights else np.einsum("bki,i->bi", e, self.Q))
+            qf = q[:, npp:].reshape(B, N, f)
+            qf[:, :, :nx] = 2.0 * e * self.Qk; qf[:, :, nx:] = 2.0 * u * self.Rk
         J = self.dF(s[:, :-1, :], u[:, :-1, :])                 # [B, N-1, nx, f]
         A = np.zeros((B, len(self.Ai)))
         A[:, self._A_id] = 1.0

@@ -7,7 +7,8 @@ method (the IPOPT / qpOASES / MIXED arms are third-p
 CasADi is not available here, so the symbolic SX expressions the reference's builders take are replaced by a tiny
 expression layer that covers what a stage-structured OCP needs: variable slices of a frame (OCPConfig.getVariable),
 the reference parameter vector, differences, and a discrete-dynamics call.  genSolver() recognises the resulting
-structure (quadratic tracking cost with diagonal weights, dynamics defects between consecutive frames) and builds the
+structure (quadratic tracking cost with diagonal weights or a general traced stage cost, dynamics defects between
+consecutive frames, per-frame path constraints) and builds the
 batched local-system evaluator (models.StageOCP) that plays the role of the CasADi-generated localSystemFunction_
 (reference src/sqp_solver/SQPOptimizationSolver.cpp:74-77).  One object may drive a batch of independent instances.
 """
@@ -59,6 +60,16 @@ class Path(Expr):
 
     def __init__(self, h, state, inp, size):
         self.h, self.state, self.inp, self.size = h, state, inp, int(size)
+
+
+class StageCost(Expr):
+    """l(state, input, reference) of one frame: a general scalar cost term given as a NumPy callable on [..., nx], [..., nu],
+    [..., nx] returning [...]; used with addScalarCost(StageCost(...)) on every frame (the last frame may use another function:
+    a terminal cost).  Stands for the arbitrary SX terms the reference sums (src/OptimalControlProblem.cpp:491-497)."""
+
+    def __init__(self, l, state, inp, reference):
+        self.l, self.state, self.inp, self.reference = l, state, inp, reference
+        self.size = 1
 
 
 # ---------------------------------------------------------------------------------------------------- OCPConfig
@@ -148,9 +159,10 @@ class OCPConfig:
 class _FacadeStageOCP(models.StageOCP):
     name = "facade_ocp"
 
-    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi, h=None, nh=0, h_lo=None, h_hi=None):
+    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi, h=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None):
         self.nx, self.nu, self._F, self._lo, self._hi = nx, nu, F, lo, hi
         self._h, self.nh, self.h_lo, self.h_hi = h, int(nh), h_lo, h_hi
+        self.lcost, self.lterm = lcost, lterm
         super().__init__(N, dt, Q, R)
 
     def F(self, s, u):
@@ -255,7 +267,8 @@ class OptimalControlProblem:
         shells out to gcc, OptimalControlProblem.cpp:263-287,602-640); returns the path of the shared library"""
         from . import codegen
         model = self.model_ if self.model_ is not None else self._compile_stage_model()
-        tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi)
+        tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi,
+                             lcost=model.lcost if model.general_cost else None, lterm=model.lterm if model.general_cost else None)
         return codegen.build_device_library(tape)
 
     def getConstraints(self):
@@ -302,13 +315,29 @@ class OptimalControlProblem:
         if s0.offset != 0 or u0.offset != nx or nx + nu != f:
             raise NotImplementedError("frame layout must be [state; input]")
         for k, c in enumerate(dyn):
-            if not (isinstance(c.a, Var) and c.a.step == k + 1 and c.a.name == s0.name and c.b.state.step == k and c.b.inp.step == k and c.b.F is F):
+            if not (isinstance(c.a, Var) and c.a.step == k + 1 and c.a.name == s0.name and c.b.state.step == k and c.b.inp.step == k and c.b.F == F):
                 raise NotImplementedError("dynamics constraints must link frame k to frame k + 1 in order")
         Qk = np.zeros((N, nx)); Rk = np.zeros((N, nu))        # per-step weights: terminal costs and ramps are ordinary here
         seenQ, seenR = set(), set()
-        for kind, w, e in self.costs_:
+        lcost = lterm = None
+        general = [c for c in self.costs_ if isinstance(c, StageCost)]
+        if general:
+            # general stage cost: one StageCost per frame, the same function on every frame but (optionally) the last
+            if len(general) != len(self.costs_) or sorted(c.state.step for c in general) != list(range(N)):
+                raise NotImplementedError("general costs: exactly one StageCost term per frame and no other cost terms")
+            general.sort(key=lambda c: c.state.step)
+            for k, c in enumerate(general):
+                if not (c.state.name == s0.name and c.inp.name == u0.name and c.inp.step == k and c.reference is self.reference_):
+                    raise NotImplementedError("a StageCost takes the state, the input and the reference of its own frame")
+            lcost = general[0].l
+            if any(c.l != lcost for c in general[:-1]):
+                raise NotImplementedError("the stage cost must be the same function on every frame except the last")
+            lterm = general[-1].l if general[-1].l != lcost else None
+            seenQ = seenR = set(range(N))
+        for term in ([] if general else self.costs_):
+            kind, w, e = term if isinstance(term, tuple) else (None, None, None)
             if kind != "weighted_square":
-                raise NotImplementedError("only addVectorCost terms are compiled")
+                raise NotImplementedError("only addVectorCost terms and StageCost terms are compiled")
             if isinstance(e, Diff) and isinstance(e.a, Var) and isinstance(e.b, Reference) and e.a.name == s0.name:
                 Qk[e.a.step] += w; seenQ.add(e.a.step)        # repeated terms on one step add up, like the SX sum (:491-497)
             elif isinstance(e, Var) and e.name == u0.name:
@@ -327,12 +356,12 @@ class OptimalControlProblem:
             h, nh = path[0].h, path[0].size
             h_lo, h_hi = self.constraintLowerBounds_[path_idx[0]], self.constraintUpperBounds_[path_idx[0]]
             for k, (c, i) in enumerate(zip(path, path_idx)):
-                if not (c.h is h and c.size == nh and c.state.step == k and c.inp.step == k and c.state.name == s0.name and c.inp.name == u0.name
+                if not (c.h == h and c.size == nh and c.state.step == k and c.inp.step == k and c.state.name == s0.name and c.inp.name == u0.name
                         and np.array_equal(self.constraintLowerBounds_[i], h_lo) and np.array_equal(self.constraintUpperBounds_[i], h_hi)):
                     raise NotImplementedError("the path constraint must be the same function and bounds on every frame")
         # rows of the compiled model: dynamics rows in frame order, then the path rows in frame order
         self._row_order = [i for _, i in sorted((self.constraints_[i].a.step, i) for i in dyn_idx)] + path_idx
-        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi)
+        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi, lcost, lterm)
 
     # -- computeOptimalTrajectory (:78-222), CUDA_SQP arm
     def computeOptimalTrajectory(self, frame, reference):

@@ -8,7 +8,7 @@ subclassing and overriding deploy_constraints_and_add_cost here."""
 import enum
 
 from . import ocp as _ocp
-from .ocp import Dynamics, OCPConfig, Path  # noqa: F401  (the expression layer standing in for casadi::SX)
+from .ocp import Dynamics, OCPConfig, Path, StageCost  # noqa: F401  (the expression layer standing in for casadi::SX)
 
 
 class SolverType(enum.Enum):

@@ -71,9 +71,11 @@ class StageEvaluator:
             for cls in (_m.DoubleIntegrator, _m.Quadrotor, _m.CartPole):
                 if isinstance(model, cls) and model.name == cls.name and type(model).F is cls.F and type(model).cdyn is cls.cdyn:
                     zoo = True
-            use_codegen = (not zoo or model.nh > 0) if codegen is None else bool(codegen)
-            if not use_codegen and (model.nh > 0 or not zoo):
-                raise ValueError("this model needs the generated evaluator (codegen=True): it is not a built-in zoo model or has a path constraint")
+            general = bool(getattr(model, "general_cost", False))
+            use_codegen = (not zoo or model.nh > 0 or general) if codegen is None else bool(codegen)
+            if not use_codegen and (model.nh > 0 or not zoo or general):
+                raise ValueError("this model needs the generated evaluator (codegen=True): it is not a built-in zoo model, or has a path "
+                                 "constraint or a general stage cost")
             _lib.check(L.mpcqp_stage_default(MODEL_IDS.get(model.name, 0) if zoo else 0, int(model.N), C.byref(d)))
             d.dt = float(model.dt)
             if model.nx > 16 or model.nu > 8:
@@ -84,7 +86,8 @@ class StageEvaluator:
             for i in range(8): d.par[i] = 0.0
             if use_codegen:
                 from . import codegen as cg
-                self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi)
+                self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi,
+                                     lcost=model.lcost if general else None, lterm=model.lterm if general else None)
                 self.library = cg.build_device_library(self.tape)
             else:
                 for i, v in enumerate(model_params(model)): d.par[i] = float(v)
@@ -97,7 +100,7 @@ class StageEvaluator:
             _lib.check(L.mpcqp_stage_create_user(C.byref(d), self.library.encode(), C.byref(self._h)))
         else:
             _lib.check(L.mpcqp_stage_create(C.byref(d), C.byref(self._h)))
-        if model is not None and getattr(model, "varying_weights", False):
+        if model is not None and getattr(model, "varying_weights", False) and not getattr(model, "general_cost", False):
             Qk = np.ascontiguousarray(model.Qk, dtype=np.float64); Rk = np.ascontiguousarray(model.Rk, dtype=np.float64)
             _lib.check(L.mpcqp_stage_set_weights(self._h, Qk.ctypes.data, Rk.ctypes.data))
         dims = np.zeros(8, np.int32)

@@ -1,0 +1,272 @@
+"""General stage costs l(s, u, r) (+ terminal cost): traced, differentiated on the tape (reverse mode), exact Hessian by one more
+forward sweep -- the counterpart of the arbitrary SX cost terms of the reference (src/OptimalControlProblem.cpp:491-497) and of its
+hessian(f, w) (src/sqp_solver/SQPOptimizationSolver.cpp:55-60).  CPU: tape derivatives against complex-step / finite differences,
+the g++ build of the generated functor, the host formulation (models.StageOCP with lcost) against the diagonal-weight one, and the
+facade with the oracle as QP backend.  GPU: device evaluation against the host formulation, the QP through the C ABI against the
+oracle, and the device-resident SQP loop against the host loop."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from optimal_control_problem_amd import codegen, models
+
+W = np.array([[4.0, 1.0, 0.0, 0.2], [1.0, 9.0, 0.5, 0.0], [0.0, 0.5, 0.6, 0.1], [0.2, 0.0, 0.1, 0.4]])   # SPD, not diagonal
+
+
+def soft_cost(s, u, r):
+    """non-diagonal tracking + a smooth one-sided penalty on the cart position + an input cost that grows with speed"""
+    e = s - r
+    quad = sum(W[i, j] * e[..., i] * e[..., j] for i in range(4) for j in range(4))
+    wall = 0.5 * np.log(1.0 + np.exp(4.0 * (s[..., 0] - 1.0)))
+    return quad + wall + (0.02 + 0.01 * s[..., 2] ** 2) * u[..., 0] ** 2 + 0.05 * u[..., 0] ** 2
+
+
+def term_cost(s, u, r):
+    e = s - r
+    return 30.0 * e[..., 0] ** 2 + 50.0 * e[..., 1] ** 2 + 4.0 * e[..., 0] * e[..., 1] + 2.0 * e[..., 2] ** 2 + 2.0 * e[..., 3] ** 2 + 0.01 * u[..., 0] ** 2
+
+
+class SoftCartPole(models.CartPole):
+    name = "cartpole_soft_cost"
+    lcost = staticmethod(soft_cost)
+    lterm = staticmethod(term_cost)
+
+
+class DenseTrackingQuadrotor(models.Quadrotor):
+    """full 12 x 12 tracking matrix: every p column couples with every state of every frame (wide hub columns in P)"""
+    name = "quadrotor_dense_tracking"
+    _M = None
+
+    @staticmethod
+    def lcost(s, u, r):
+        Wq = DenseTrackingQuadrotor._M
+        e = s - r
+        v = 0.0
+        for i in range(12):
+            for j in range(12):
+                if Wq[i, j] != 0.0:
+                    v = v + Wq[i, j] * e[..., i] * e[..., j]
+        return v + 0.1 * (u[..., 0] ** 2 + u[..., 1] ** 2 + u[..., 2] ** 2 + u[..., 3] ** 2)
+
+
+def _dense_tracking_matrix():
+    rng = np.random.default_rng(4)
+    G = rng.normal(0, 0.3, (12, 12))
+    return np.diag([10.0] * 3 + [1.0] * 6 + [0.1] * 3) + 0.1 * G @ G.T
+
+
+DenseTrackingQuadrotor._M = _dense_tracking_matrix()
+
+
+def test_gradient_tape_hessian_mask_and_generated_functor(built):
+    L, G = codegen.trace_cost(soft_cost, 4, 1, 4)
+    mask = codegen.hessian_mask(G)
+    rng = np.random.default_rng(0)
+    lib = C.CDLL(codegen.build_host_library(codegen.trace(models.CartPole(5).F, 4, 1, lcost=soft_cost, lterm=term_cost)))
+    lib.user_host_cost.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
+    assert lib.user_host_has_cost() == 1
+    Hsum = np.zeros((9, 9))
+    for _ in range(4):
+        w = rng.normal(0, 0.6, 9)
+        g = np.array(G.evaluate(list(w)), float)
+        cs = np.array([np.imag(L.evaluate(list(w + 1e-30j * np.eye(9)[i]))[0]) / 1e-30 for i in range(9)])
+        assert np.abs(g - cs).max() <= 1e-13 * (1 + np.abs(cs).max())
+        H = np.array([np.imag(np.array(G.evaluate(list(w + 1e-30j * np.eye(9)[i])))) / 1e-30 for i in range(9)]).T
+        assert np.abs(H - H.T).max() <= 1e-12 * (1 + np.abs(H).max())
+        Hsum += np.abs(H)
+        val = np.zeros(1); gr = np.zeros(9); he = np.zeros((9, 9))
+        s, u, r = w[:4].copy(), w[4:5].copy(), w[5:].copy()
+        lib.user_host_cost(s.ctypes.data, u.ctypes.data, r.ctypes.data, 0, val.ctypes.data, gr.ctypes.data, he.ctypes.data)
+        assert abs(val[0] - L.evaluate(list(w))[0]) <= 1e-14 * (1 + abs(val[0]))
+        assert np.abs(gr - g).max() <= 1e-13 * (1 + np.abs(g).max()) and np.abs(he - H).max() <= 1e-12 * (1 + np.abs(H).max())
+        lib.user_host_cost(s.ctypes.data, u.ctypes.data, r.ctypes.data, 1, val.ctypes.data, gr.ctypes.data, he.ctypes.data)
+        assert abs(val[0] - term_cost(s, u, r)) <= 1e-13 * (1 + abs(val[0]))
+    assert not (Hsum[~mask] != 0).any()                     # the structural mask covers every nonzero
+    assert not mask[4, 5:].any() and not mask[1, 4]         # u does not couple with r, nor with the pole angle
+    assert mask[0, 0] and mask[2, 4] and mask[0, 5]
+
+
+def test_general_cost_formulation_matches_diagonal_weights():
+    """the same objective given as a general cost: identical dense P, q and objective as the zoo model's closed forms"""
+    zoo = models.CartPole(8, 0.02)
+    Q, R = zoo.Q.copy(), zoo.R.copy()
+
+    class AsGeneral(models.CartPole):
+        @staticmethod
+        def lcost(s, u, r):
+            e = s - r
+            return sum(Q[i] * e[..., i] ** 2 for i in range(4)) + R[0] * u[..., 0] ** 2
+
+    gen = AsGeneral(8, 0.02)
+    assert gen.general_cost and not zoo.general_cost
+    rng = np.random.default_rng(2)
+    B = 3
+    p = rng.normal(0, 0.3, (B, 4)); x = rng.normal(0, 0.4, (B, zoo.nvar))
+    lbx, ubx, lbg, ubg = zoo.stacked_bounds(x[:, :zoo.f].copy())
+    a = zoo.local_system(p, x, lbx, ubx, lbg, ubg); b = gen.local_system(p, x, lbx, ubx, lbg, ubg)
+    for i in range(B):
+        Pa, Aa = a.dense(i); Pb, Ab = b.dense(i)
+        assert np.abs(Pa - Pb).max() <= 1e-12 and np.array_equal(Aa, Ab)
+    assert np.abs(a.q - b.q).max() <= 1e-12 and np.array_equal(a.l, b.l) and np.array_equal(a.u, b.u)
+    assert np.abs(zoo.objective(p, x) - gen.objective(p, x)).max() <= 1e-12
+    assert np.array_equal(gen.Pi, zoo.Pi)                   # the traced structure is exactly the diagonal-weight one
+
+
+def test_general_cost_local_system_against_finite_differences():
+    mdl = SoftCartPole(6, 0.02)
+    rng = np.random.default_rng(5)
+    p = rng.normal(0, 0.3, (2, 4)); x = rng.normal(0, 0.5, (2, mdl.nvar))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    f = lambda w: mdl.objective(w[None, :4], w[None, 4:])[0]
+    w = np.concatenate([p[1], x[1]]); I = np.eye(len(w))
+    g = np.array([(f(w + 1e-6 * e) - f(w - 1e-6 * e)) / 2e-6 for e in I])
+    assert np.abs(g - ls.q[1]).max() <= 1e-6 * (1 + np.abs(g).max())
+    Pd, _ = ls.dense(1)
+    assert np.abs(Pd - Pd.T).max() <= 1e-12
+    gq = lambda w: mdl.local_system(w[None, :4], w[None, 4:], lbx[:1], ubx[:1], lbg[:1], ubg[:1]).q[0]
+    H = np.array([(gq(w + 1e-6 * e) - gq(w - 1e-6 * e)) / 2e-6 for e in I]).T
+    assert np.abs(H - Pd).max() <= 1e-6 * (1 + np.abs(Pd).max())
+    assert np.linalg.eigvalsh(Pd).min() > -1e-9             # this cost is convex: the QP is accepted
+
+
+FACADE_YAML = """
+  discretization_settings: {dt: 0.02, horizon: 8}
+  solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                    SQP_settings: {alpha: 0.7, step_num: 3}}
+  OCP_variables:
+    - {name: state, size: 4, lower_bound: [-2.4, -.inf, -.inf, -.inf], upper_bound: [2.4, .inf, .inf, .inf]}
+    - {name: input, size: 1, lower_bound: [-20.0], upper_bound: [20.0]}
+"""
+
+
+def _facade_class():
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem, StageCost
+    cp = models.CartPole(8, 0.02)
+
+    class SoftCartPoleOCP(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_; ref = self.setReference(4); N = cfg.getHorizon()
+            for k in range(N):
+                st, inp = cfg.getVariable(k, "state"), cfg.getVariable(k, "input")
+                self.addScalarCost(StageCost(soft_cost if k < N - 1 else term_cost, st, inp, ref))
+                if k < N - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(cp.F, st, inp))
+
+    return SoftCartPoleOCP
+
+
+def test_facade_stage_cost_with_oracle_backend(built):
+    import yaml
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 2
+    ocp = _facade_class()(yaml.safe_load(FACADE_YAML % "false"), batch=B, qp_solver=OracleCuCaQP(batch=B))
+    ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    mdl = ocp.model_
+    assert mdl.general_cost and mdl.lterm is term_cost and mdl.lcost is soft_cost
+    twin = SoftCartPole(8, 0.02)
+    assert np.array_equal(mdl.Pi, twin.Pi) and np.array_equal(mdl.Ai, twin.Ai)
+    rng = np.random.default_rng(8)
+    frame = np.concatenate([rng.normal(0, 0.2, (B, 4)), np.zeros((B, 1))], axis=1); ref = np.zeros((B, 4))
+    traj = ocp.computeOptimalTrajectory(frame, ref)
+    assert np.isfinite(traj).all()
+    assert np.abs(traj[:, :5] - frame).max() <= 0.3 ** 3 * np.abs(frame).max() + 5e-3     # pinned frame after three damped steps from x = 0
+    x0 = np.tile(frame, (1, 8))
+    assert (mdl.objective(ref, traj) < mdl.objective(ref, x0) + 1e-9).all() or np.abs(mdl.constraints(traj)).max() < np.abs(mdl.constraints(x0)).max() + 1e-9
+    # a second function in the middle of the horizon is refused
+    from optimal_control_problem_amd.ocp import StageCost
+    bad = _facade_class()(yaml.safe_load(FACADE_YAML % "false"), batch=1, qp_solver=object())
+    bad.deployConstraintsAndAddCost()
+    c = bad.costs_[3]; bad.costs_[3] = StageCost(lambda s, u, r: u[..., 0] ** 2, c.state, c.inp, c.reference)
+    with pytest.raises(NotImplementedError, match="same function"):
+        bad._compile_stage_model()
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+def _dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def _close(a, b, tol):
+    """elementwise |a - b| <= tol * max(1, |b|), with infinities required to match exactly"""
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin) and np.array_equal(a[~fin], b[~fin])
+    return (np.abs(a[fin] - b[fin]) <= tol * np.maximum(1.0, np.abs(b[fin]))).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,N,B", [(SoftCartPole, 12, 37), (DenseTrackingQuadrotor, 6, 9)], ids=["cartpole_soft", "quadrotor_dense"])
+def test_general_cost_on_device_matches_host(built, cls, N, B):
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    mdl = cls(N, 0.02)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = rng.normal(0, 0.2, (B, mdl.nx))
+    if mdl.nu == 4:
+        x.reshape(B, N, mdl.f)[:, :, 12:] += mdl.hover_thrust
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ref = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    ev = StageEvaluator(mdl)
+    assert ev.library is not None and ev.nnzP == len(mdl.Pi) and (ev.Pi == mdl.Pi).all() and (ev.Pp == mdl.Pp).all()
+    out = ev.eval(_dev(p), _dev(x), _dev(lbx), _dev(ubx), _dev(lbg), _dev(ubg))
+    for k, r in (("P", ref.P), ("q", ref.q), ("A", ref.A), ("l", ref.l), ("u", ref.u)):
+        assert _close(out[k].cpu().numpy(), r, 1e-12), k
+    f, g = ev.merit(_dev(p), _dev(x))
+    assert _close(f.cpu().numpy(), mdl.objective(p, x), 1e-12)
+    assert _close(g.cpu().numpy(), np.abs(mdl.constraints(x)).max(axis=1), 1e-11)
+    with pytest.raises(Exception, match="stage cost"):
+        from optimal_control_problem_amd import _lib
+        Qk = np.ones((N, mdl.nx)); Rk = np.ones((N, mdl.nu))
+        _lib.check(_lib.lib().mpcqp_stage_set_weights(ev._h, Qk.ctypes.data, Rk.ctypes.data))
+    ev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,N,B", [(SoftCartPole, 12, 24), (DenseTrackingQuadrotor, 8, 12)], ids=["cartpole_soft", "quadrotor_dense"])
+def test_general_cost_qp_matches_oracle(built, cls, N, B):
+    """the QP of a general-cost local system (dense frame blocks and wide p columns in P) through the C ABI against the oracle"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    mdl = cls(N, 0.02)
+    rng = np.random.default_rng(6)
+    X = np.zeros((B, N, mdl.f)); X[:, :, :mdl.nx] = rng.normal(0, 0.1, (B, N, mdl.nx))
+    X[:, :, mdl.nx:] = rng.normal(0, 0.2, (B, N, mdl.nu)) + (mdl.hover_thrust if mdl.nu == 4 else 0.0)
+    x = X.reshape(B, -1); p = rng.normal(0, 0.1, (B, mdl.nx))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    want = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings(eps_abs=1e-3, eps_rel=1e-3, max_iter=10000), nthreads=8)
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, eps_abs=1e-3, eps_rel=1e-3, max_iter=10000)
+    qp.update(_dev(ls.P), _dev(ls.q), _dev(ls.A), _dev(ls.l), _dev(ls.u)); qp.solve(); got = qp.get(); qp.close()
+    assert np.array_equal(got["status"], want["status"]) and (got["status"] == 1).all()
+    assert np.array_equal(got["iters"], want["iters"])
+    assert np.abs(got["x"] - want["x"]).max() <= 1e-6 * (1 + np.abs(want["x"]).max())
+
+
+@pytest.mark.gpu
+def test_general_cost_device_sqp_equals_host_sqp_and_facade(built):
+    import yaml
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    B, N = 16, 12
+    mdl = SoftCartPole(N, 0.02)
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 0.2, (B, mdl.nvar)); p = np.zeros((B, 4))
+    frame0 = x[:, :mdl.f].copy()
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, p=p)
+    host = SQPOptimizationSolver(mdl, {"max_iter": 4, "alpha": 0.7}, batch=B); dev = DeviceSQPOptimizationSolver(mdl, {"max_iter": 4, "alpha": 0.7}, batch=B)
+    host.setInitialGuess(x); dev.setInitialGuess(x)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * (1 + np.abs(rh["x"]).max())
+    assert np.abs(rd["f"] - rh["f"]).max() <= 1e-6 * (1 + np.abs(rh["f"]).max())
+    assert np.abs(mdl.constraints(rh["x"])).max() < 0.1 * np.abs(mdl.constraints(x)).max()      # the loop closes the dynamics defects
+    host.qpSolver_.close(); dev.close()
+    # facade: gen_code false (host evaluation) against true (device-resident, the generated library carries the cost)
+    frame = np.concatenate([rng.normal(0, 0.2, (B, 4)), np.zeros((B, 1))], axis=1); ref = np.zeros((B, 4))
+    res = {}
+    for flag in ("false", "true"):
+        ocp = _facade_class()(yaml.safe_load(FACADE_YAML % flag), batch=B)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        res[flag] = ocp.computeOptimalTrajectory(frame, ref)
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
