@@ -218,6 +218,8 @@ void mpcqp_stage_destroy(mpcqp_stage *s);
 int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk);
 /* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
 int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);
+/* 1 when the evaluator was generated with its own stage cost (mpcqp_stage_create_user above), 0 for diagonal tracking weights */
+int mpcqp_stage_has_cost(const mpcqp_stage *s);
 /* CSC sparsity of P (n x n, both triangles, as CasADi hands it to CuCaQP) and A = [I; dg/dw] (m x n): the arrays
  * mpcqp_create takes.  Pp, Ap: n + 1 entries; Pi: nnz(P); Ai: nnz(A).  Host pointers. */
 int mpcqp_stage_pattern(const mpcqp_stage *s, int *Pp, int *Pi, int *Ap, int *Ai);

@@ -222,6 +222,9 @@ struct StageModel { int builtin = -1; std::string library; double par[8] = {0};
 struct Dynamics { StageModel model; Var state, input; int size() const { return state.size(); } };   // F(state_k, input_k)
 struct Path { StageModel model; Var state, input; int rows = 0; int size() const { return rows; } };  // h(state_k, input_k)
 struct Cost { int kind = 0; Var var; bool minusReference = false; std::vector<double> weight; };       // sum_i w_i e_i^2
+// general cost term l(state_k, input_k, reference) of one frame, carried by the generated library of the dynamics (codegen.trace with
+// lcost / lterm): the stand-in for an arbitrary SX term of the reference (src/OptimalControlProblem.cpp:491-497)
+struct StageCost { StageModel model; Var state, input; Reference reference; int size() const { return 1; } };
 }  // namespace ocp_expr
 
 // ------------------------------------------------------------------------------------------------ OCPConfig
@@ -280,7 +283,7 @@ class OptimalControlProblem {
  public:
   enum class SolverType { IPOPT, SQP, CUDA_SQP, MIXED };
   using Var = ocp_expr::Var; using Reference = ocp_expr::Reference; using Diff = ocp_expr::Diff;
-  using Dynamics = ocp_expr::Dynamics; using Path = ocp_expr::Path; using StageModel = ocp_expr::StageModel;
+  using Dynamics = ocp_expr::Dynamics; using Path = ocp_expr::Path; using StageModel = ocp_expr::StageModel; using StageCost = ocp_expr::StageCost;
 
   std::unique_ptr<OCPConfig> OCPConfigPtr_;
   Reference reference_;
@@ -315,6 +318,7 @@ class OptimalControlProblem {
     if ((int)param.size() != cost.size()) { std::cout << "损失的符号向量和参数向量维度不一致" << std::endl; return; }
     costs_.push_back(ocp_expr::Cost{0, cost, false, param});
   }
+  void addScalarCost(const StageCost &cost) { stageCosts_.push_back(cost); }          // :491-497
   void addEquationConstraint(const std::string &constraintName, const Var &leftSX, const Dynamics &rightSX) {
     if (leftSX.size() != rightSX.size()) throw std::invalid_argument("SX used for constraints has different dimension!");   // :472-474
     dynamics_.push_back({leftSX, rightSX}); constraintNames_.insert(constraintNames_.end(), leftSX.size(), constraintName);
@@ -326,7 +330,7 @@ class OptimalControlProblem {
     paths_.push_back({expression, lowerBound, upperBound}); constraintNames_.insert(constraintNames_.end(), expression.size(), constraintName);
   }
   size_t getConstraints() const { return dynamics_.size() + paths_.size(); }
-  size_t getCostFunction() const { return costs_.size(); }
+  size_t getCostFunction() const { return costs_.size() + stageCosts_.size(); }
 
   // genSolver (:224-442), CUDA_SQP arm :391-401
   void genSolver() {
@@ -357,7 +361,19 @@ class OptimalControlProblem {
       else if (!c.minusReference && c.var.name == u0.name) { for (int i = 0; i < nu; i++) Rk[(size_t)c.var.step * nu + i] += c.weight[i]; hasR[c.var.step] = 1; }
       else throw std::runtime_error("cost term not recognised: use (state - reference) and (input) terms");
     }
-    for (int k = 0; k < N; k++) if (!hasQ[k] || !hasR[k]) throw std::runtime_error("tracking and input costs must be added for every step");
+    const bool general = !stageCosts_.empty();
+    if (general) {
+      // the objective lives in the generated library: one StageCost per frame, from the library that also holds the dynamics
+      if (!costs_.empty() || (int)stageCosts_.size() != N || mdl.builtin >= 0) throw std::runtime_error("general costs: exactly one StageCost term per frame, no other cost terms, dynamics from a generated library");
+      std::vector<char> got(N, 0);
+      for (auto &c : stageCosts_) {
+        const int k = c.state.step;
+        if (k < 0 || k >= N || got[k] || c.input.step != k || c.state.name != s0.name || c.input.name != u0.name || c.model.library != mdl.library)
+          throw std::runtime_error("a StageCost takes the state and the input of its own frame and the library of the dynamics");
+        got[k] = 1;
+      }
+    }
+    for (int k = 0; k < N && !general; k++) if (!hasQ[k] || !hasR[k]) throw std::runtime_error("tracking and input costs must be added for every step");
     if (reference_.size() != nx) throw std::runtime_error("reference must have the state's dimension");
     mpcqp_stage_desc d;
     if (mpcqp_stage_default(mdl.builtin >= 0 ? mdl.builtin : 0, N, &d) != MPCQP_OK) throw std::runtime_error(mpcqp_strerror(MPCQP_ERR_ARG));
@@ -371,7 +387,10 @@ class OptimalControlProblem {
     if (solver_->ng() != (N - 1) * nx + N * nh_) throw std::runtime_error("the compiled model's path constraint differs from the one added");
     bool same = true;
     for (int k = 1; k < N && same; k++) { for (int i = 0; i < nx; i++) same &= Qk[(size_t)k * nx + i] == Qk[i]; for (int i = 0; i < nu; i++) same &= Rk[(size_t)k * nu + i] == Rk[i]; }
-    if (!same) solver_->setWeights(Qk, Rk);
+    if (general != solver_->generalCost())
+      throw std::runtime_error(general ? "StageCost terms were added but the library was generated without a stage cost"
+                                       : "the library carries its own stage cost: add StageCost terms instead of addVectorCost");
+    if (!same && !general) solver_->setWeights(Qk, Rk);
     nx_ = nx; nu_ = nu;
   }
 
@@ -420,7 +439,7 @@ class OptimalControlProblem {
   int batch_ = 1, maxIter_ = 1000, stepNum_ = 10, nx_ = 0, nu_ = 0, nh_ = 0;
   double alpha_ = 0.1; bool warmStart_ = true, verbose_ = true, genCode_ = false, loadLib_ = false, firstTime_ = true;
   SolverType solverType_ = SolverType::CUDA_SQP;
-  std::vector<std::pair<Var, Dynamics>> dynamics_; std::vector<PathRow> paths_; std::vector<ocp_expr::Cost> costs_;
+  std::vector<std::pair<Var, Dynamics>> dynamics_; std::vector<PathRow> paths_; std::vector<ocp_expr::Cost> costs_; std::vector<StageCost> stageCosts_;
   std::vector<std::string> constraintNames_;
   std::vector<double> optimalTrajectory_;
   std::unique_ptr<StageSQP> solver_;

@@ -47,6 +47,7 @@ class StageSQP {
   int nx() const { return dims_[0]; } int nu() const { return dims_[1]; } int np() const { return dims_[2]; }
   int n() const { return dims_[3]; } int m() const { return dims_[4]; } int nnzP() const { return dims_[5]; }
   int nnzA() const { return dims_[6]; } int nvar() const { return dims_[7]; } int ng() const { return m() - n(); }
+  bool generalCost() const { return mpcqp_stage_has_cost(ocp_) == 1; }   // the generated library carries its own stage cost
 
   // per-frame diagonal weights (terminal costs): Qk [horizon * nx], Rk [horizon * nu]
   void setWeights(const std::vector<double> &Qk, const std::vector<double> &Rk) {

@@ -202,6 +202,8 @@ int mpcqp_stage_dims(const mpcqp_stage *s, int *o) {
   return MPCQP_OK;
 }
 
+int mpcqp_stage_has_cost(const mpcqp_stage *s) { return s && s->general_cost ? 1 : 0; }
+
 int mpcqp_stage_pattern(const mpcqp_stage *s, int *Pp, int *Pi, int *Ap, int *Ai) {
   if (!s || !Pp || !Pi || !Ap || !Ai) return mpcqp_set_error(MPCQP_ERR_ARG, "null argument");
   std::copy(s->Pp.begin(), s->Pp.end(), Pp); std::copy(s->Pi.begin(), s->Pi.end(), Pi);

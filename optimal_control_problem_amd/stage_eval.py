@@ -29,6 +29,7 @@ def _bind(L):
     L.mpcqp_stage_destroy.restype = None
     L.mpcqp_stage_set_weights.argtypes = [vp, dp, dp]
     L.mpcqp_stage_dims.argtypes = [vp, vp]
+    L.mpcqp_stage_has_cost.argtypes = [vp]
     L.mpcqp_stage_pattern.argtypes = [vp, vp, vp, vp, vp]
     L.mpcqp_stage_eval.argtypes = [vp, C.c_int] + [dp] * 11 + [vp]
     L.mpcqp_stage_merit.argtypes = [vp, C.c_int, dp, dp, dp, dp, vp]
@@ -107,6 +108,7 @@ class StageEvaluator:
         _lib.check(L.mpcqp_stage_dims(self._h, dims.ctypes.data))
         self.nx, self.nu, self.np, self.n, self.m, self.nnzP, self.nnzA, self.nvar = [int(v) for v in dims]
         self.ng = self.m - self.n
+        self.general_cost = bool(L.mpcqp_stage_has_cost(self._h))
         self.Pp = np.zeros(self.n + 1, np.int32); self.Pi = np.zeros(self.nnzP, np.int32)
         self.Ap = np.zeros(self.n + 1, np.int32); self.Ai = np.zeros(self.nnzA, np.int32)
         _lib.check(L.mpcqp_stage_pattern(self._h, self.Pp.ctypes.data, self.Pi.ctypes.data, self.Ap.ctypes.data, self.Ai.ctypes.data))

@@ -111,9 +111,51 @@ static int test_run() {
   return 0;
 }
 
+// general stage cost from a generated library (argv[2], made by codegen.trace(F, ..., lcost=, lterm=)): same YAML, the library's
+// dynamics are the double integrator's; prints the trajectories for the caller to compare with the Python facade
+class GeneralCostOCP : public OptimalControlProblem {
+ public:
+  GeneralCostOCP(const YamlNode &n, int batch, const std::string &lib) : OptimalControlProblem(n, batch), lib_(lib) {}
+  void deployConstraintsAndAddCost() override {
+    const OCPConfig &cfg = *OCPConfigPtr_;
+    const int N = cfg.getHorizon();
+    Reference ref = setReference(2);
+    const StageModel plant = StageModel::fromLibrary(lib_);
+    for (int k = 0; k < N; k++) {
+      if (vectorCosts_) { addVectorCost({10.0, 1.0}, cfg.getVariable(k, "state") - ref); addVectorCost({0.1}, cfg.getVariable(k, "input")); }
+      else addScalarCost(StageCost{plant, cfg.getVariable(k, "state"), cfg.getVariable(k, "input"), ref});
+    }
+    for (int k = 0; k < N - 1; k++)
+      addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics{plant, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")});
+  }
+  std::string lib_;
+  bool vectorCosts_ = false;
+};
+
+static int test_cost(const char *lib) {
+  const int B = 4;
+  GeneralCostOCP ocp(YamlNode::Load(kYaml)["optimal_control_problem"], B, lib);
+  ocp.deployConstraintsAndAddCost();
+  EXPECT(ocp.getCostFunction() == 20);
+  ocp.genSolver();
+  std::vector<double> frame((size_t)B * 3), ref((size_t)B * 2, 0.0);
+  for (int b = 0; b < B; b++) { frame[b * 3] = -0.8 + 0.5 * b; frame[b * 3 + 1] = 0.2; frame[b * 3 + 2] = 0.0; ref[b * 2] = 0.1 * b; }
+  const std::vector<double> &traj = ocp.computeOptimalTrajectory(frame, ref);
+  EXPECT((int)traj.size() == B * 60);
+  for (int b = 0; b < B; b++) { std::printf("traj"); for (int i = 0; i < 60; i++) std::printf(" %.17g", traj[(size_t)b * 60 + i]); std::printf("\n"); }
+  // the library carries its own cost: diagonal addVectorCost terms on top of it are refused
+  GeneralCostOCP mixed(YamlNode::Load(kYaml)["optimal_control_problem"], B, lib);
+  mixed.vectorCosts_ = true;
+  mixed.deployConstraintsAndAddCost();
+  EXPECT(throws<std::runtime_error>([&] { mixed.genSolver(); }));
+  std::printf("cost ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   try {
     if (argc > 1 && std::strcmp(argv[1], "config") == 0) return test_config();
+    if (argc > 2 && std::strcmp(argv[1], "cost") == 0) return test_cost(argv[2]);
     return test_run();
   } catch (const std::exception &e) { std::fprintf(stderr, "uncaught: %s\n", e.what()); return 1; }
 }

@@ -2,6 +2,7 @@
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "cucaqp_cpp_test")
@@ -64,3 +65,53 @@ def test_cpp_ocp_on_gpu(built):
     """a C++ subclass written like the reference's examples (deployConstraintsAndAddCost / genSolver / computeOptimalTrajectory)"""
     r = subprocess.run([OCP_EXE, "run"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "run ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def _di_step(s, u):
+    return np.stack([s[..., 0] + 0.05 * s[..., 1] + 0.00125 * u[..., 0], s[..., 1] + 0.05 * u[..., 0]], axis=-1)
+
+
+def _di_stage_cost(s, u, r):
+    e = s - r
+    return 10.0 * e[..., 0] ** 2 + e[..., 1] ** 2 + e[..., 0] * e[..., 1] + (0.1 + 0.05 * e[..., 1] ** 2) * u[..., 0] ** 2
+
+
+def _di_terminal_cost(s, u, r):
+    e = s - r
+    return 200.0 * e[..., 0] ** 2 + 20.0 * e[..., 1] ** 2 + 0.1 * u[..., 0] ** 2
+
+
+@pytest.mark.gpu
+def test_cpp_ocp_general_cost_equals_python_facade(built):
+    """C++ OptimalControlProblem with StageCost terms carried by a generated library (dynamics + stage cost + terminal cost) against
+    the Python facade on the same problem, both device-resident"""
+    import yaml
+    from optimal_control_problem_amd import codegen
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem, StageCost
+    lib = codegen.build_device_library(codegen.trace(_di_step, 2, 1, lcost=_di_stage_cost, lterm=_di_terminal_cost))
+    r = subprocess.run([OCP_EXE, "cost", lib], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cost ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    got = np.array([[float(v) for v in line.split()[1:]] for line in r.stdout.splitlines() if line.startswith("traj")])
+    text = """
+      discretization_settings: {dt: 0.05, horizon: 20}
+      solver_settings: {verbose: false, gen_code: true, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 1.0, step_num: 2}}
+      OCP_variables:
+        - {name: state, size: 2, lower_bound: [-.inf, -2.0], upper_bound: [.inf, 2.0]}
+        - {name: input, size: 1, lower_bound: [-1.0], upper_bound: [1.0]}
+    """
+
+    class DI(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_; ref = self.setReference(2); N = cfg.getHorizon()
+            for k in range(N):
+                st, inp = cfg.getVariable(k, "state"), cfg.getVariable(k, "input")
+                self.addScalarCost(StageCost(_di_stage_cost if k < N - 1 else _di_terminal_cost, st, inp, ref))
+                if k < N - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(_di_step, st, inp))
+
+    B = 4
+    ocp = DI(yaml.safe_load(text), batch=B); ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    frame = np.array([[-0.8 + 0.5 * b, 0.2, 0.0] for b in range(B)]); ref = np.array([[0.1 * b, 0.0] for b in range(B)])
+    want = ocp.computeOptimalTrajectory(frame, ref)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9 * (1 + np.abs(want).max())
