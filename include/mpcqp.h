@@ -34,7 +34,8 @@ extern "C" {
 #define MPCQP_DUAL_INFEASIBLE_INACCURATE 6
 #define MPCQP_MAX_ITER_REACHED 7
 #define MPCQP_NON_CVX 9
-#define MPCQP_UNSOLVED 11
+#define MPCQP_UNSOLVED 11      /* also: data refused -- an instance with l_i > u_i on some row is not solved (OSQP's setup validation,
+                                * which makes CuCaQP::initSolver return false, CuCaQP.cpp:183-197): 0 iterations, NaN in x, y, z */
 
 #define MPCQP_MEM_HOST 0      /* pointer is host memory (pageable or pinned) */
 #define MPCQP_MEM_DEVICE 1    /* pointer is device memory on the handle's GPU */

@@ -108,6 +108,15 @@ class CuCaQP {
   bool initSolver() {                                            // reference CuCaQP.cpp:183-197
     isInitialized_ = false;
     if (Pp_.empty() || Ap_.empty() || q_.empty() || l_.empty() || u_.empty()) { std::cerr << "Error: Failed to initialize solver." << std::endl; return false; }
+    // osqp_setup refuses l_i > u_i, so OsqpEigen's initSolver fails (reference CuCaQP.cpp:183-197); with a batch, instances are refused
+    // one by one (status MPCQP_UNSOLVED) and only a batch without any valid instance fails here
+    bool anyValid = numOfConstraints_ == 0;
+    for (int b = 0; b < batch_ && !anyValid; b++) {
+      bool crossed = false;
+      for (int i = 0; i < numOfConstraints_; i++) crossed |= l_[(size_t)b * numOfConstraints_ + i] > u_[(size_t)b * numOfConstraints_ + i];
+      anyValid = !crossed;
+    }
+    if (!anyValid) { std::cerr << "Error: Failed to initialize solver. (lower bound greater than upper bound)" << std::endl; return false; }
     int rc = MPCQP_OK;
     if (!handle_ || patternChanged_ || dirty_) {
       clearSolver();

@@ -1433,6 +1433,24 @@ extern "C" __global__ void __launch_bounds__(WAVE) mpcqp_blockops_kernel(const d
   if (lane == 0) *fail = ok ? 0 : 1;
 }
 
+// OSQP validates its data at setup and refuses a problem with l_i > u_i (OSQP_DATA_VALIDATION_ERROR: OsqpEigen's initSolver,
+// reference src/sqp_solver/CuCaQP.cpp:183-197, returns false and nothing is solved).  Batched form of that refusal, run behind the
+// solve kernel so that the hot kernels carry no extra state: an instance with crossed bounds reports MPCQP_UNSOLVED with 0
+// iterations and NaN in x, y, z and the residuals (rho, info[3], is left for a kept workspace).  One wave per instance.
+extern "C" __global__ void __launch_bounds__(256) mpcqp_validate_kernel(int batch, int n, int m, const double *__restrict__ l, long sl,
+                                                                          const double *__restrict__ u, long su, double *x, double *y, double *z,
+                                                                          int *status, int *iters, double *info) {
+  const int lane = threadIdx.x & (WAVE - 1), b = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  if (b >= batch) return;
+  const double *lb = l + (long)b * sl, *ub = u + (long)b * su;
+  int crossed = 0;
+  for (int i = lane; i < m; i += WAVE) crossed |= lb[i] > ub[i];
+  if (!__any(crossed)) return;
+  for (int j = lane; j < n; j += WAVE) x[(long)b * n + j] = NAN;
+  for (int i = lane; i < m; i += WAVE) { y[(long)b * m + i] = NAN; z[(long)b * m + i] = NAN; }
+  if (lane == 0) { status[b] = MPCQP_UNSOLVED; iters[b] = 0; info[4L * b] = NAN; info[4L * b + 1] = NAN; info[4L * b + 2] = NAN; }
+}
+
 // Dispatch hint for the NEXT solve on a handle: instances ordered by descending iteration count of the solve that just
 // finished (counting sort over iters / unit).  Instances are independent, so the order changes no result -- it only lets the
 // long ones start first instead of wherever they sit in the batch: with one QP per workgroup and 25 / 50 / 75-iteration
@@ -1825,6 +1843,11 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
+  if (h->m > 0) {
+    hipLaunchKernelGGL(mpcqp_validate_kernel, dim3((h->batch + 3) / 4), dim3(256), 0, s, h->batch, h->n, h->m, io.l, io.sl, io.u, io.su, io.x, io.y, io.z,
+                       io.status, io.iters, io.info);
+    HIPCHK(hipGetLastError());
+  }
   if (h->lpt && h->batch > 1) {   // order of the next solve from this solve's iteration counts
     const int nxt = h->order_cur == 0 ? 1 : 0;
     hipLaunchKernelGGL(mpcqp_order_kernel, dim3(1), dim3(1024), 0, s, (const int *)h->oiters, h->order[nxt], h->batch, std::max(1, h->st.check_termination));
@@ -1854,6 +1877,11 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
   else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
+  if (m > 0) {
+    hipLaunchKernelGGL(mpcqp_validate_kernel, dim3((count + 3) / 4), dim3(256), 0, s, count, h->n, h->m, io.l, io.sl, io.u, io.su, io.x, io.y, io.z,
+                       io.status, io.iters, io.info);
+    HIPCHK(hipGetLastError());
+  }
   return MPCQP_OK;
 }
 

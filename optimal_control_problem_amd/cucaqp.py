@@ -195,6 +195,11 @@ class CuCaQP:
         self._clear_solver()
         if self._P is None or self._A is None or self.gradient is None or self.lowerBound is None or self.upperBound is None:
             return _err("Failed to initialize solver.")
+        lo = np.asarray(self.lowerBound, float).reshape(-1, self.numOfConstraints_); up = np.asarray(self.upperBound, float).reshape(-1, self.numOfConstraints_)
+        if self.numOfConstraints_ and (lo > up).any(axis=1).all():
+            # osqp_setup refuses l_i > u_i, so OsqpEigen's initSolver fails (reference CuCaQP.cpp:183-197); with a batch, instances
+            # are refused one by one (status MPCQP_UNSOLVED) and only a batch without any valid instance fails here
+            return _err("Failed to initialize solver. (lower bound greater than upper bound)")
         key = (self.numOfVariables_, self.numOfConstraints_, self.batch, self._P[0].tobytes(), self._P[1].tobytes(),
                self._A[0].tobytes(), self._A[1].tobytes(), tuple(sorted((k, v) for k, v in self._kw.items())))
         try:

@@ -614,6 +614,22 @@ static void store(work_t *w, int b, double *x, double *y, double *z, int *status
   if (info) { info[4 * b] = w->obj; info[4 * b + 1] = w->prim_res; info[4 * b + 2] = w->dual_res; info[4 * b + 3] = w->rho; }
 }
 
+/* OSQP validates the data at setup and refuses a problem with l_i > u_i (osqp_setup returns OSQP_DATA_VALIDATION_ERROR, so
+ * OsqpEigen's initSolver -- reference src/sqp_solver/CuCaQP.cpp:183-197 -- returns false and nothing is solved).  Batched form of
+ * that refusal: the instance reports ORC_UNSOLVED with 0 iterations and NaN in x, y, z and the residuals. */
+static void refuse_crossed_bounds(int n, int m, const double *l, const double *u, int b, double *x, double *y, double *z, int *status,
+                                  int *iters, double *info) {
+  int crossed = 0;
+  for (int i = 0; i < m; i++) crossed |= l[i] > u[i];
+  if (!crossed) return;
+  if (x) for (int j = 0; j < n; j++) x[(size_t)b * n + j] = NAN;
+  if (y) for (int i = 0; i < m; i++) y[(size_t)b * m + i] = NAN;
+  if (z) for (int i = 0; i < m; i++) z[(size_t)b * m + i] = NAN;
+  if (status) status[b] = ORC_UNSOLVED;
+  if (iters) iters[b] = 0;
+  if (info) info[4 * b] = info[4 * b + 1] = info[4 * b + 2] = NAN;
+}
+
 int orc_solve_batch(const orc_pattern *pt, const orc_settings *st, int batch,
                     const double *Px, long sP, const double *q, long sq, const double *Ax, long sA,
                     const double *l, long sl, const double *u, long su,
@@ -641,6 +657,7 @@ int orc_solve_batch_rho(const orc_pattern *pt, const orc_settings *st, int batch
       solve_one(w, Px + (size_t)b * sP, q + (size_t)b * sq, Ax + (size_t)b * sA, l + (size_t)b * sl, u + (size_t)b * su,
                 x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, rho0 ? rho0[b] : 0.0, 0);
       store(w, b, x, y, z, status, iters, info);
+      refuse_crossed_bounds(pt->n, pt->m, l + (size_t)b * sl, u + (size_t)b * su, b, x, y, z, status, iters, info);
     }
     work_free(w);
   }
@@ -680,6 +697,7 @@ int orc_state_solve(orc_state *s, int vectors_only,
     solve_one(w, vectors_only ? NULL : Px + (size_t)b * sP, q + (size_t)b * sq, vectors_only ? NULL : Ax + (size_t)b * sA,
               l + (size_t)b * sl, u + (size_t)b * su, x0 ? x0 + (size_t)b * pt->n : NULL, y0 ? y0 + (size_t)b * pt->m : NULL, 0.0, vectors_only);
     store(w, b, x, y, z, status, iters, info);
+    refuse_crossed_bounds(pt->n, pt->m, l + (size_t)b * sl, u + (size_t)b * su, b, x, y, z, status, iters, info);
   }
   s->solved = 1;
   return 0;

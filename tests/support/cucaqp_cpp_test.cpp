@@ -15,6 +15,9 @@ int main() {
   const int Pp[] = {0, 1, 2}, Pi[] = {0, 1}; const double Pv[] = {2.0, 2.0};
   const int Ap[] = {0, 2, 4}, Ai[] = {0, 2, 1, 2}; const double Av[] = {1, 1, 1, 1};
   const double q[] = {0, 0}, l[] = {-50, -100, 1}, u[] = {50, 100, 1};
+  const double lx[] = {-50, -100, 2}, ux[] = {50, 100, 1};   // crossed bounds: refused like osqp_setup refuses them (CuCaQP.cpp:183-197)
+  qp.setSystem({2, 2, Pp, Pi, Pv}, q, {3, 2, Ap, Ai, Av}, lx, ux);
+  if (qp.initSolver() || qp.solve()) return 1;
   qp.setSystem({2, 2, Pp, Pi, Pv}, q, {3, 2, Ap, Ai, Av}, l, u);
   if (!qp.initSolver()) return 3;
   if (!qp.solve()) return 1;

@@ -229,6 +229,11 @@ def test_cucaqp_call_sequence_and_errors(built, capsys):
     assert qp.getStatus()[0] == 1 and qp.getIterations()[0] == 25
     qp.printSolverData()
     assert "scaling c" in capsys.readouterr().out
+    # crossed bounds: osqp_setup refuses them, so initSolver returns false and solve() has nothing to solve (CuCaQP.cpp:183-203)
+    lo = ls.l[0].copy(); up = ls.u[0].copy(); lo[0], up[0] = 1.0, -1.0
+    qp.setSystem([(ls.Pp, ls.Pi, ls.P[0]), ls.q[0], (ls.Ap, ls.Ai, ls.A[0]), lo, up])
+    assert qp.initSolver() is False and "lower bound greater than upper bound" in capsys.readouterr().err
+    assert qp.solve() is False and "not initialized" in capsys.readouterr().err
     qp.close()
 
 
@@ -542,3 +547,82 @@ def test_long_horizons_vs_oracle(built, name, N, B):
     from optimal_control_problem_amd.batch_qp import BatchQP
     qp = BatchQP(ls.n, ls.m, 4096, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
     assert info["variant"] >= 100
+
+
+INF = float("inf")
+
+
+def _edge_problems():
+    """small QPs at the edges of the interface: one variable, no constraints, no quadratic term (LP), a structurally present but
+    numerically zero row and column of A, rows loose on both sides, and crossed bounds (l > u: refused like OSQP's setup does)"""
+    from optimal_control_problem_amd.models import _csc_from_dense_mask
+    out = []
+
+    def add(name, Pd, Ad, q, l, u, Pmask=None, Amask=None):
+        n = Pd.shape[0]; m = Ad.shape[0]
+        Pm = (Pd != 0) if Pmask is None else Pmask; Am = (Ad != 0) if Amask is None else Amask
+        Pp, Pi = _csc_from_dense_mask(Pm)
+        Ap, Ai = _csc_from_dense_mask(Am) if m else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32))
+        out.append(dict(name=name, n=n, m=m, Pp=Pp, Pi=Pi, Ap=Ap, Ai=Ai, P=np.atleast_2d(Pd.T[Pm.T]), A=np.atleast_2d(Ad.T[Am.T]) if m else np.zeros((1, 0)),
+                        q=np.atleast_2d(np.asarray(q, float)), l=np.atleast_2d(np.asarray(l, float)) if m else np.zeros((1, 0)),
+                        u=np.atleast_2d(np.asarray(u, float)) if m else np.zeros((1, 0))))
+
+    add("one_variable", np.array([[2.0]]), np.array([[1.0]]), [1.0], [-1.0], [1.0])
+    add("no_constraints", np.diag([2.0, 1.0]), np.zeros((0, 2)), [1.0, -1.0], [], [])
+    add("lp", np.zeros((2, 2)), np.eye(2), [1.0, -1.0], [-1, -1], [1, 1])
+    add("zero_row_and_column", np.eye(2), np.array([[1.0, 0.0], [0.0, 0.0]]), [1.0, -1.0], [-1, -1], [1, 1], Amask=np.ones((2, 2), bool))
+    add("loose_rows", np.eye(2), np.eye(2), [1.0, -1.0], [-INF, -INF], [INF, INF])
+    add("crossed_bounds", np.eye(2), np.eye(2), [1.0, -1.0], [1.0, -1.0], [-1.0, 1.0])
+    return out
+
+
+@pytest.mark.parametrize("prob", _edge_problems(), ids=lambda p: p["name"])
+def test_interface_edge_cases(built, prob):
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    n, m = prob["n"], prob["m"]
+    pat = orc.Pattern(n, m, prob["Pp"], prob["Pi"], prob["Ap"], prob["Ai"])
+    ref = pat.solve(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], orc.default_settings())
+    qp = BatchQP(n, m, 1, prob["Pp"], prob["Pi"], prob["Ap"], prob["Ai"])
+    qp.update(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"]); qp.solve(); got = qp.get(); qp.close()
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["iters"], ref["iters"])
+    if prob["name"] == "crossed_bounds":
+        assert got["status"][0] == 11 and got["iters"][0] == 0 and np.isnan(got["x"]).all() and np.isnan(got["y"]).all() and np.isnan(ref["x"]).all()
+    else:
+        assert got["status"][0] == 1
+        assert np.abs(got["x"] - ref["x"]).max() <= 1e-6 * (1 + np.abs(ref["x"]).max())
+        if m:
+            assert np.abs(got["y"] - ref["y"]).max() <= 1e-6 * (1 + np.abs(ref["y"]).max())
+
+
+def test_crossed_bounds_refuse_only_their_instance(built):
+    """l > u on one row of some instances of a batch: those report MPCQP_UNSOLVED / NaN (OSQP refuses such data at setup), every other
+    instance is solved exactly as without them; the same through the kept workspace (new vectors with crossed bounds, then valid ones)"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    mdl, ls, _ = models.make_workload("double_integrator", 24)
+    l = ls.l.copy(); u = ls.u.copy()
+    bad = np.array([3, 10, 23]); row = mdl.n + 5
+    l[bad, row] = 1.0; u[bad, row] = -1.0
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    clean = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings())
+    ref = pat.solve(ls.P, ls.q, ls.A, l, u, orc.default_settings())
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.keep_workspace(True)
+    qp.update(ls.P, ls.q, ls.A, l, u); qp.solve(); got = qp.get()
+    ok = np.setdiff1d(np.arange(ls.batch), bad)
+    assert (got["status"][bad] == 11).all() and (got["iters"][bad] == 0).all() and np.isnan(got["x"][bad]).all() and np.isnan(got["z"][bad]).all()
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["iters"], ref["iters"])
+    assert np.array_equal(got["status"][ok], clean["status"][ok]) and np.abs(got["x"][ok] - clean["x"][ok]).max() <= 1e-6 * (1 + np.abs(clean["x"]).max())
+    # kept workspace: crossed bounds arrive with new vectors on other instances, then everything is valid again
+    st = orc.State(pat, ls.batch, orc.default_settings()); st.solve(ls.P, ls.q, ls.A, l, u)
+    l2 = ls.l.copy(); u2 = ls.u.copy(); l2[[1, 3], row] = 2.0; u2[[1, 3], row] = -2.0
+    r2 = st.solve_vectors(ls.q, l2, u2)
+    qp.update_vectors(ls.q, l2, u2); qp.solve(); g2 = qp.get()
+    assert np.array_equal(g2["status"], r2["status"]) and np.array_equal(g2["iters"], r2["iters"]) and (g2["status"][[1, 3]] == 11).all()
+    good = np.setdiff1d(np.arange(ls.batch), [1, 3])
+    assert np.abs(g2["x"][good] - r2["x"][good]).max() <= 1e-6 * (1 + np.abs(r2["x"][good]).max())
+    r3 = st.solve_vectors(ls.q, ls.l, ls.u)
+    qp.update_vectors(ls.q, ls.l, ls.u); qp.solve(); g3 = qp.get(); qp.close()
+    assert np.array_equal(g3["status"], r3["status"]) and np.array_equal(g3["iters"], r3["iters"]) and (g3["status"] == 1).all()
+    assert np.abs(g3["x"] - r3["x"]).max() <= 1e-6 * (1 + np.abs(r3["x"]).max())
