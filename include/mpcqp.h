@@ -217,6 +217,12 @@ void mpcqp_stage_destroy(mpcqp_stage *s);
  * differ by step, reference readme.md:121-128).  NULL, NULL returns to desc.Q, desc.R.  MPCQP_ERR_ARG for an evaluator generated
  * with its own stage cost. */
 int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk);
+/* Per-frame bounds of the path constraint, lo / hi [horizon * nh] host pointers, copied: what mpcqp_stage_merit measures violations
+ * against when the bounds differ by frame -- a terminal constraint is a path constraint that is loose (-inf, +inf) on every frame
+ * but the last (addInequalityConstraint is called per frame in the reference, src/OptimalControlProblem.cpp:448-470, so bounds may
+ * differ by frame).  The QP itself takes its bounds from lbg / ubg of mpcqp_stage_eval either way.  NULL, NULL returns to the
+ * bounds baked into the generated library. */
+int mpcqp_stage_set_path_bounds(mpcqp_stage *s, const double *lo, const double *hi);
 /* dims[8] = {nx, nu, np, n, m, nnz(P), nnz(A), horizon * (nx + nu)} */
 int mpcqp_stage_dims(const mpcqp_stage *s, int *dims8);
 /* 1 when the evaluator was generated with its own stage cost (mpcqp_stage_create_user above), 0 for diagonal tracking weights */

@@ -17,7 +17,7 @@ STATUS = {1: "solved", 2: "solved_inaccurate", 3: "primal_infeasible", 4: "prima
 EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_update", "mpcqp_warm_start", "mpcqp_keep_workspace", "mpcqp_update_vectors", "mpcqp_set_rho", "mpcqp_set_dispatch_hint", "mpcqp_solve", "mpcqp_solve_host",
            "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms",
            "mpcqp_plan_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
-           "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
+           "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_set_path_bounds", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
            "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step"]
 
 

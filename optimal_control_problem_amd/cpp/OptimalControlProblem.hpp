@@ -385,6 +385,11 @@ class OptimalControlProblem {
     if (solver_->nx() != nx || solver_->nu() != nu) throw std::runtime_error("the compiled model's state / input sizes differ from the YAML frame");
     nh_ = paths_.empty() ? 0 : paths_[0].expr.size();
     if (solver_->ng() != (N - 1) * nx + N * nh_) throw std::runtime_error("the compiled model's path constraint differs from the one added");
+    if (nh_ > 0) {   // bounds may differ by frame (a terminal constraint is loose on every frame but the last): tell the violation measure
+      std::vector<double> lo((size_t)N * nh_), hi((size_t)N * nh_);
+      for (auto &p : paths_) for (int r = 0; r < nh_; r++) { lo[(size_t)p.expr.state.step * nh_ + r] = p.lo[r]; hi[(size_t)p.expr.state.step * nh_ + r] = p.hi[r]; }
+      solver_->setPathBounds(lo, hi);
+    }
     bool same = true;
     for (int k = 1; k < N && same; k++) { for (int i = 0; i < nx; i++) same &= Qk[(size_t)k * nx + i] == Qk[i]; for (int i = 0; i < nu; i++) same &= Rk[(size_t)k * nu + i] == Rk[i]; }
     if (general != solver_->generalCost())

@@ -55,6 +55,11 @@ class StageSQP {
     check(mpcqp_stage_set_weights(ocp_, Qk.data(), Rk.data()), "mpcqp_stage_set_weights");
   }
 
+  // per-frame bounds of the path constraint [horizon * nh] for the violation measure (terminal constraints: loose but on the last frame)
+  void setPathBounds(const std::vector<double> &lo, const std::vector<double> &hi) {
+    check(mpcqp_stage_set_path_bounds(ocp_, lo.data(), hi.data()), "mpcqp_stage_set_path_bounds");
+  }
+
   void setInitialGuess(const std::vector<double> &x) {            // extension: the reference always starts from zero
     need(x.size(), (size_t)batch_ * nvar(), "x");
     hip(hipMemcpy(x_, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice));

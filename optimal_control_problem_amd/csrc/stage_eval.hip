@@ -29,6 +29,7 @@ struct mpcqp_stage {
   std::vector<int> Pp, Pi, Ap, Ai;
   int *dPp = nullptr, *dAp = nullptr;
   double *dQk = nullptr, *dRk = nullptr;
+  double *dhlo = nullptr, *dhhi = nullptr;   // per-frame path bounds (mpcqp_stage_set_path_bounds)
   unsigned char *dmask = nullptr;     // Hessian structure of a generated general stage cost
   void *user_lib = nullptr;           // dlopen handle of a generated dynamics library (model == MPCQP_MODEL_USER)
   user_eval_fn user_eval = nullptr;
@@ -109,7 +110,7 @@ static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh
   if (hipMemcpy(s->dPp, s->Pp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->dAp, s->Ap.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
     return mpcqp_set_error(MPCQP_ERR_HIP, "upload of the column pointers failed");
-  sd.Pp = s->dPp; sd.Ap = s->dAp; sd.Qk = nullptr; sd.Rk = nullptr; sd.hmask = nullptr;
+  sd.Pp = s->dPp; sd.Ap = s->dAp; sd.Qk = nullptr; sd.Rk = nullptr; sd.hmask = nullptr; sd.h_lok = nullptr; sd.h_hik = nullptr;
   if (cost_mask) {
     const size_t mb = (size_t)(sd.f + sd.nx) * (sd.f + sd.nx);
     if (hipMalloc(&s->dmask, mb) != hipSuccess || hipMemcpy(s->dmask, cost_mask, mb, hipMemcpyHostToDevice) != hipSuccess)
@@ -175,6 +176,8 @@ void mpcqp_stage_destroy(mpcqp_stage *s) {
   if (s->dQk) (void)hipFree(s->dQk);
   if (s->dRk) (void)hipFree(s->dRk);
   if (s->dmask) (void)hipFree(s->dmask);
+  if (s->dhlo) (void)hipFree(s->dhlo);
+  if (s->dhhi) (void)hipFree(s->dhhi);
   if (s->user_lib) dlclose(s->user_lib);
   delete s;
 }
@@ -192,6 +195,22 @@ int mpcqp_stage_set_weights(mpcqp_stage *s, const double *Qk, const double *Rk) 
   MPCQP_HIPCHK(hipMemcpy(s->dQk, Qk, bq, hipMemcpyHostToDevice));
   MPCQP_HIPCHK(hipMemcpy(s->dRk, Rk, br, hipMemcpyHostToDevice));
   sd.Qk = s->dQk; sd.Rk = s->dRk;
+  return MPCQP_OK;
+}
+
+int mpcqp_stage_set_path_bounds(mpcqp_stage *s, const double *lo, const double *hi) {
+  if (!s) return mpcqp_set_error(MPCQP_ERR_ARG, "stage handle is null");
+  if ((lo == nullptr) != (hi == nullptr)) return mpcqp_set_error(MPCQP_ERR_ARG, "give both bound arrays or neither");
+  StageDev &sd = s->sd;
+  if (sd.nh == 0) return mpcqp_set_error(MPCQP_ERR_ARG, "this evaluator has no path constraint");
+  MPCQP_HIPCHK(hipSetDevice(s->device));
+  if (!lo) { sd.h_lok = nullptr; sd.h_hik = nullptr; return MPCQP_OK; }
+  const size_t bytes = (size_t)sd.N * sd.nh * sizeof(double);
+  if (!s->dhlo) MPCQP_HIPCHK(hipMalloc(&s->dhlo, bytes));
+  if (!s->dhhi) MPCQP_HIPCHK(hipMalloc(&s->dhhi, bytes));
+  MPCQP_HIPCHK(hipMemcpy(s->dhlo, lo, bytes, hipMemcpyHostToDevice));
+  MPCQP_HIPCHK(hipMemcpy(s->dhhi, hi, bytes, hipMemcpyHostToDevice));
+  sd.h_lok = s->dhlo; sd.h_hik = s->dhhi;
   return MPCQP_OK;
 }
 

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "stage_models.hpp"
 
-#define STAGE_ABI_VERSION 4
+#define STAGE_ABI_VERSION 5
 
 struct StageDev {
   int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows
@@ -18,6 +18,7 @@ struct StageDev {
   const int *Pp, *Ap;   // device copies of the column pointers
   const double *Qk, *Rk;   // optional per-frame diagonal weights [N * nx], [N * nu] (device; NULL = Q, R for every frame)
   const unsigned char *hmask;   // general stage cost (M::has_cost): Hessian structure over [s; u; r], (f + nx)^2 bytes (device)
+  const double *h_lok, *h_hik;  // optional per-frame path-constraint bounds [N * nh] (device; NULL = h_lo, h_hi on every frame)
 };
 
 template <class M>
@@ -191,7 +192,10 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
       double hv[M::nh];
       M::template H<double>(s, uu, hv);
 #pragma unroll
-      for (int i = 0; i < M::nh; i++) gmax = fmax(gmax, fmax(sd.h_lo[i] - hv[i], hv[i] - sd.h_hi[i]));
+      for (int i = 0; i < M::nh; i++) {
+        const double lo = sd.h_lok ? sd.h_lok[k * M::nh + i] : sd.h_lo[i], hi = sd.h_hik ? sd.h_hik[k * M::nh + i] : sd.h_hi[i];
+        gmax = fmax(gmax, fmax(lo - hv[i], hv[i] - hi));
+      }
     }
   }
   for (int o = 32; o >= 1; o >>= 1) { cost += __shfl_xor(cost, o, 64); gmax = fmax(gmax, __shfl_xor(gmax, o, 64)); }

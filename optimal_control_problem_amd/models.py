@@ -145,8 +145,14 @@ class StageOCP:
 
     nx = 0; nu = 0; name = "ocp"
     # optional per-stage path constraint lo <= h(s_k, u_k) <= hi, nh rows per frame (addInequalityConstraint, reference
-    # src/OptimalControlProblem.cpp:448-470); rows are stacked behind the dynamics rows: c = [p; x; g; h]
+    # src/OptimalControlProblem.cpp:448-470); rows are stacked behind the dynamics rows: c = [p; x; g; h].  h_lo, h_hi: [nh] for
+    # every frame, or [N, nh] when they differ by frame (a terminal constraint is loose, -inf / +inf, on every frame but the last)
     nh = 0; h_lo = None; h_hi = None
+
+    def path_bounds(self):
+        """([N, nh], [N, nh]) bounds of the path constraint per frame"""
+        return (np.broadcast_to(np.asarray(self.h_lo, float), (self.N, self.nh)).copy(),
+                np.broadcast_to(np.asarray(self.h_hi, float), (self.N, self.nh)).copy())
 
     def hfun(self, s, u):
         """[..., nh] path-constraint values; must accept complex input (override together with nh, h_lo, h_hi)"""
@@ -392,7 +398,8 @@ class StageOCP:
         lbx[:, :self.f] = frame0; ubx[:, :self.f] = frame0
         lbg = np.zeros((B, self.ng)); ubg = np.zeros((B, self.ng))
         if self.nh:
-            lbg[:, self.ngd:] = np.tile(np.asarray(self.h_lo, float), self.N); ubg[:, self.ngd:] = np.tile(np.asarray(self.h_hi, float), self.N)
+            lo, hi = self.path_bounds()
+            lbg[:, self.ngd:] = lo.ravel(); ubg[:, self.ngd:] = hi.ravel()
         return lbx, ubx, lbg, ubg
 
 

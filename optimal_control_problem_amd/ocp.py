@@ -267,7 +267,8 @@ class OptimalControlProblem:
         shells out to gcc, OptimalControlProblem.cpp:263-287,602-640); returns the path of the shared library"""
         from . import codegen
         model = self.model_ if self.model_ is not None else self._compile_stage_model()
-        tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi,
+        h_lo, h_hi = model.path_bounds() if model.nh else (None, None)
+        tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, h_lo[0] if model.nh else None, h_hi[0] if model.nh else None,
                              lcost=model.lcost if model.general_cost else None, lterm=model.lterm if model.general_cost else None)
         return codegen.build_device_library(tape)
 
@@ -354,11 +355,12 @@ class OptimalControlProblem:
         if path:
             path.sort(key=lambda c: c.state.step); path_idx.sort(key=lambda i: self.constraints_[i].state.step)
             h, nh = path[0].h, path[0].size
-            h_lo, h_hi = self.constraintLowerBounds_[path_idx[0]], self.constraintUpperBounds_[path_idx[0]]
             for k, (c, i) in enumerate(zip(path, path_idx)):
-                if not (c.h == h and c.size == nh and c.state.step == k and c.inp.step == k and c.state.name == s0.name and c.inp.name == u0.name
-                        and np.array_equal(self.constraintLowerBounds_[i], h_lo) and np.array_equal(self.constraintUpperBounds_[i], h_hi)):
-                    raise NotImplementedError("the path constraint must be the same function and bounds on every frame")
+                if not (c.h == h and c.size == nh and c.state.step == k and c.inp.step == k and c.state.name == s0.name and c.inp.name == u0.name):
+                    raise NotImplementedError("the path constraint must be the same function on every frame (its bounds may differ by frame)")
+            h_lo = np.stack([self.constraintLowerBounds_[i] for i in path_idx]); h_hi = np.stack([self.constraintUpperBounds_[i] for i in path_idx])
+            if (h_lo == h_lo[0]).all() and (h_hi == h_hi[0]).all():
+                h_lo, h_hi = h_lo[0], h_hi[0]
         # rows of the compiled model: dynamics rows in frame order, then the path rows in frame order
         self._row_order = [i for _, i in sorted((self.constraints_[i].a.step, i) for i in dyn_idx)] + path_idx
         return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi, lcost, lterm)

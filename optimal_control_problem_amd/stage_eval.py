@@ -28,6 +28,7 @@ def _bind(L):
     L.mpcqp_stage_destroy.argtypes = [vp]
     L.mpcqp_stage_destroy.restype = None
     L.mpcqp_stage_set_weights.argtypes = [vp, dp, dp]
+    L.mpcqp_stage_set_path_bounds.argtypes = [vp, dp, dp]
     L.mpcqp_stage_dims.argtypes = [vp, vp]
     L.mpcqp_stage_has_cost.argtypes = [vp]
     L.mpcqp_stage_pattern.argtypes = [vp, vp, vp, vp, vp]
@@ -87,7 +88,8 @@ class StageEvaluator:
             for i in range(8): d.par[i] = 0.0
             if use_codegen:
                 from . import codegen as cg
-                self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, model.h_lo, model.h_hi,
+                h_lo, h_hi = model.path_bounds()
+                self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, h_lo[0] if model.nh else None, h_hi[0] if model.nh else None,
                                      lcost=model.lcost if general else None, lterm=model.lterm if general else None)
                 self.library = cg.build_device_library(self.tape)
             else:
@@ -104,6 +106,9 @@ class StageEvaluator:
         if model is not None and getattr(model, "varying_weights", False) and not getattr(model, "general_cost", False):
             Qk = np.ascontiguousarray(model.Qk, dtype=np.float64); Rk = np.ascontiguousarray(model.Rk, dtype=np.float64)
             _lib.check(L.mpcqp_stage_set_weights(self._h, Qk.ctypes.data, Rk.ctypes.data))
+        if model is not None and model.nh and np.ndim(model.h_lo) == 2:      # bounds that differ by frame (terminal constraints)
+            lo, hi = [np.ascontiguousarray(v, dtype=np.float64) for v in model.path_bounds()]
+            _lib.check(L.mpcqp_stage_set_path_bounds(self._h, lo.ctypes.data, hi.ctypes.data))
         dims = np.zeros(8, np.int32)
         _lib.check(L.mpcqp_stage_dims(self._h, dims.ctypes.data))
         self.nx, self.nu, self.np, self.n, self.m, self.nnzP, self.nnzA, self.nvar = [int(v) for v in dims]

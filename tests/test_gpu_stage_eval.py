@@ -338,3 +338,74 @@ def test_per_frame_weights_on_device(built):
         assert ocp.model_.varying_weights and ocp.model_.Qk[-1, 0] == 400.0
         res[flag] = ocp.computeOptimalTrajectory(frame, refv)
     assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
+
+
+def test_terminal_constraint_as_path_with_per_frame_bounds(built):
+    """a path constraint whose bounds differ by frame: loose everywhere but on the last frame = a terminal constraint (the cart ends
+    inside a box, at rest).  mpcqp_stage_set_path_bounds feeds the violation measure; device SQP = host SQP; facade = the same."""
+    import yaml
+    from optimal_control_problem_amd.ocp import Dynamics, OptimalControlProblem, Path
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    N, B = 10, 12
+    lo = np.full((N, 2), -np.inf); hi = np.full((N, 2), np.inf)
+    lo[-1] = [-0.05, -0.1]; hi[-1] = [0.05, 0.1]
+
+    def terminal_box(s, u):
+        return np.stack([s[..., 0], s[..., 2]], axis=-1)      # cart position and velocity
+
+    class CP(models.CartPole):
+        name = "cartpole_terminal_box"; nh = 2; h_lo = lo; h_hi = hi
+        hfun = staticmethod(terminal_box)
+
+    mdl = CP(N, 0.05)
+    rng = np.random.default_rng(12)
+    x = rng.normal(0, 0.1, (B, mdl.nvar)); p = np.zeros((B, 4))
+    frame0 = x[:, :mdl.f].copy(); frame0[:, 0] = rng.uniform(-0.3, 0.3, B); frame0[:, 1] = rng.normal(0, 0.05, B)
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    assert np.isinf(lbg[:, mdl.ngd:-2]).all() and np.array_equal(ubg[0, -2:], [0.05, 0.1])
+    ev = StageEvaluator(mdl)
+    f, g = ev.merit(_dev(p), _dev(x))
+    hv = mdl.path_values(x).reshape(B, N, 2)
+    viol = np.maximum(np.maximum(lo - hv, hv - hi).max(axis=(1, 2)), np.abs(mdl.constraints(x)).max(axis=1))
+    assert _close(g.cpu().numpy(), viol, 1e-11)
+    ev.close()
+    arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, p=p)
+    opts = {"max_iter": 6, "alpha": 0.8}
+    host = SQPOptimizationSolver(mdl, opts, batch=B); dev = DeviceSQPOptimizationSolver(mdl, opts, batch=B)
+    host.setInitialGuess(x); dev.setInitialGuess(x)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * (1 + np.abs(rh["x"]).max())
+    last = rd["x"].reshape(B, N, mdl.f)[:, -1]
+    assert (np.abs(last[:, 0]) <= 0.05 + 2e-2).all() and (np.abs(last[:, 2]) <= 0.1 + 2e-2).all()
+    assert float(dev.gmax.max()) <= 5e-2
+    host.qpSolver_.close(); dev.close()
+    # the facade: the same Path on every frame, bounds loose but on the last
+    text = """
+      discretization_settings: {dt: 0.05, horizon: 10}
+      solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 0.8, step_num: 6}}
+      OCP_variables:
+        - {name: state, size: 4, lower_bound: [-2.4, -.inf, -.inf, -.inf], upper_bound: [2.4, .inf, .inf, .inf]}
+        - {name: input, size: 1, lower_bound: [-20.0], upper_bound: [20.0]}
+    """
+    cp = models.CartPole(N, 0.05); Fd = cp.F
+
+    class Terminal(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_; ref = self.setReference(4); Nh = cfg.getHorizon()
+            for k in range(Nh):
+                st, inp = cfg.getVariable(k, "state"), cfg.getVariable(k, "input")
+                self.addVectorCost([1.0, 10.0, 0.1, 0.1], st - ref); self.addVectorCost([0.01], inp)
+                self.addInequalityConstraint("terminal_box", lo[k], Path(terminal_box, st, inp, 2), hi[k])
+                if k < Nh - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(Fd, st, inp))
+
+    frame = frame0[:, :5].copy(); frame[:, 4] = 0.0
+    res = {}
+    for flag in ("false", "true"):
+        ocp = Terminal(yaml.safe_load(text % flag), batch=B)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert np.shape(ocp.model_.h_lo) == (N, 2)
+        res[flag] = ocp.computeOptimalTrajectory(frame, np.zeros((B, 4)))
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
