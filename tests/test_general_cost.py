@@ -270,3 +270,54 @@ def test_general_cost_device_sqp_equals_host_sqp_and_facade(built):
         ocp.deployConstraintsAndAddCost(); ocp.genSolver()
         res[flag] = ocp.computeOptimalTrajectory(frame, ref)
     assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
+
+
+@pytest.mark.gpu
+def test_maximum_sizes_on_device(built):
+    """the evaluator's limits at once: nx = 16, nu = 8, nh = 16 path rows, a general cost over all 40 local variables, a terminal cost;
+    device = host formulation, and the resulting QP through the C ABI = the oracle"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    from oracle import oracle as orc
+    rng = np.random.default_rng(21)
+    Am = np.eye(16) + 0.05 * rng.normal(size=(16, 16)); Bm = 0.1 * rng.normal(size=(16, 8))
+    Wm = rng.normal(size=(24, 24)); Wm = Wm @ Wm.T / 24 + np.eye(24); Cm = 0.3 * rng.normal(size=(16, 24))
+
+    class Big(models.StageOCP):
+        nx = 16; nu = 8; name = "max_sizes"; nh = 16; h_lo = [-3.0] * 16; h_hi = [3.0] * 16
+
+        def F(self, s, u):
+            return np.stack([sum(Am[i, j] * s[..., j] for j in range(16)) + sum(Bm[i, j] * u[..., j] for j in range(8)) + 0.01 * np.sin(s[..., i]) for i in range(16)], axis=-1)
+
+        def hfun(self, s, u):
+            w = [s[..., j] for j in range(16)] + [u[..., j] for j in range(8)]
+            return np.stack([sum(Cm[i, j] * w[j] for j in range(24)) for i in range(16)], axis=-1)
+
+        @staticmethod
+        def lcost(s, u, r):
+            w = [s[..., j] - r[..., j] for j in range(16)] + [u[..., j] for j in range(8)]
+            return sum(Wm[i, j] * w[i] * w[j] for i in range(24) for j in range(24)) + 0.1 * np.log(1.0 + np.exp(w[0] + w[23]))
+
+        @staticmethod
+        def lterm(s, u, r):
+            return sum(5.0 * (s[..., j] - r[..., j]) ** 2 for j in range(16)) + sum(0.1 * u[..., j] ** 2 for j in range(8))
+
+    N, B = 4, 10
+    mdl = Big(N, 0.1, np.zeros(16), np.zeros(8))
+    assert mdl.cost_mask.all()                               # every pair of local variables couples
+    x = rng.normal(0, 0.2, (B, mdl.nvar)); p = rng.normal(0, 0.1, (B, 16))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ref = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    ev = StageEvaluator(mdl)
+    assert (ev.n, ev.m, ev.nnzP) == (mdl.n, mdl.m, len(mdl.Pi)) and (ev.Pi == mdl.Pi).all() and (ev.Ai == mdl.Ai).all()
+    out = ev.eval(_dev(p), _dev(x), _dev(lbx), _dev(ubx), _dev(lbg), _dev(ubg))
+    for k, r in (("P", ref.P), ("q", ref.q), ("A", ref.A), ("l", ref.l), ("u", ref.u)):
+        assert _close(out[k].cpu().numpy(), r, 1e-11), k
+    f, g = ev.merit(_dev(p), _dev(x))
+    assert _close(f.cpu().numpy(), mdl.objective(p, x), 1e-12)
+    qp = BatchQP(ev.n, ev.m, B, ev.Pp, ev.Pi, ev.Ap, ev.Ai)
+    qp.update(out["P"], out["q"], out["A"], out["l"], out["u"]); qp.solve(); got = qp.get(); qp.close(); ev.close()
+    want = orc.Pattern(ref.n, ref.m, ref.Pp, ref.Pi, ref.Ap, ref.Ai).solve(ref.P, ref.q, ref.A, ref.l, ref.u, orc.default_settings(), nthreads=8)
+    assert np.array_equal(got["status"], want["status"]) and np.array_equal(got["iters"], want["iters"])
+    ok = np.isfinite(want["x"])
+    assert np.array_equal(np.isfinite(got["x"]), ok) and np.abs(got["x"][ok] - want["x"][ok]).max() <= 1e-6 * (1 + np.abs(want["x"][ok]).max())
