@@ -19,6 +19,7 @@ struct DevRes {
   int nphase, ntemp, nconst, rext;   // nconst constant blocks behind the factor blocks (slot nblk = -I), rext partial-sum doubles behind the solve vector
   const int *lv_ptr, *lv_diag, *lw_ptr, *lw_slot, *lw_g, *lu_ptr, *lu_dst, *lu_tmp, *lu_b, *g_ptr, *g_seg;
   int n_seg, nlev; long stage;
+  int tmp_alias;   // global-block plans: the factorisation's temp tiles alias w (plan.hpp gb_tmp_alias)
 };
 
 template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
@@ -408,7 +409,11 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
     double *ni = cx.BL + (long)pl.nblk * BLK;
     for (int e = tid; e < BLK; e += NT) ni[e] = (e / BS == e % BS) ? -1.0 : 0.0;
   }
-  for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
+  if (rs.tmp_alias) {   // the temp tiles lived in w: its rho vector is gone, recompute it (bit-identical) from the bounds
+    for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
+  } else {
+    for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
+  }
   bsync<NW>();
 #ifdef MPCQP_TIMING
   cx.fts[2] += __builtin_amdgcn_s_memtime() - f2;
@@ -569,6 +574,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (GB && ZYG) {   // z and y are only ever indexed by their own row: in the slab they cost two coalesced streams per iteration and
     cx.Z = ws + pl.o_Zg; cx.Y = ws + pl.o_Yg; cx.W = rend;   // free 2 * mpad doubles of LDS (one more workgroup per CU for long horizons)
   } else { cx.Z = rend; cx.Y = cx.Z + pl.mpad; cx.W = cx.Y + pl.mpad; }
+  if (GB && rs.tmp_alias) cx.TMP = cx.W;
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 32 * NW);     // [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);

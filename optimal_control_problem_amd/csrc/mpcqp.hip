@@ -231,7 +231,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       }
       h->occ4 = h->gblocks && !h->zyg && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
       // LDS between 40 and 53 KiB: three workgroups per CU fit, so the instance compiled for three waves per SIMD (168 VGPRs, no
-      // spills, 8 blocks in flight) replaces the 128-VGPR one (cart-pole N=100: 92.9k -> 95.8k QP/s; at 32 KiB it loses, 589k -> 551k)
+      // spills, 8 blocks in flight) replaces the 128-VGPR one (at 42 KiB 92.9k -> 95.8k QP/s on cart-pole N=100, which now fits four per CU
+      // because the temp tiles alias w, plan.hpp gb_tmp_alias: 76.2 -> 73.2 ms per 8192; at 32 KiB it loses, 589k -> 551k)
+      // (with z and y in the slab the 168-VGPR instance at three per CU also beats the 128-VGPR one at four: quadrotor N=50 23.9 vs 26.0 ms)
       h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
@@ -262,7 +264,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     UP(upload(h, rp.lv_ptr, &dr.lv_ptr)); UP(upload(h, rp.lv_diag, &dr.lv_diag)); UP(upload(h, rp.lw_ptr, &dr.lw_ptr));
     UP(upload(h, rp.lw_slot, &dr.lw_slot)); UP(upload(h, rp.lw_g, &dr.lw_g)); UP(upload(h, rp.lu_ptr, &dr.lu_ptr));
     UP(upload(h, rp.lu_dst, &dr.lu_dst)); UP(upload(h, rp.lu_tmp, &dr.lu_tmp)); UP(upload(h, rp.lu_b, &dr.lu_b));
-    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = h->gblocks ? res_stage_doubles_gb(rp) : res_stage_doubles(pl, rp);
+    UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = h->gblocks ? res_stage_doubles_gb(pl, rp) : res_stage_doubles(pl, rp);
+    dr.tmp_alias = h->gblocks && gb_tmp_alias(pl, rp) ? 1 : 0;
   }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;

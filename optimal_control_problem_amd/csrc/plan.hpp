@@ -646,11 +646,14 @@ inline long res_stage_doubles(const Plan &pl, const ResPlan &rp) {
   return (std::max(blocks, ell) + 15) / 16 * 16;
 }
 // the same kernels with the factor blocks left in the HBM slab: LDS holds temp tiles + vectors + schedule only
-inline long res_stage_doubles_gb(const ResPlan &rp) { return ((long)rp.ntemp * BLK + 15) / 16 * 16; }
+// The temp tiles are live only inside the level loop of the factorisation, where w (= rho z - y between factorisations, the rho
+// vector during one) is dead if rho is recomputed from the bounds at the end: with mpad >= ntemp * 256 they alias w and cost no LDS.
+inline bool gb_tmp_alias(const Plan &pl, const ResPlan &rp) { return (long)pl.mpad >= (long)rp.ntemp * BLK; }
+inline long res_stage_doubles_gb(const Plan &pl, const ResPlan &rp) { return gb_tmp_alias(pl, rp) ? 0 : ((long)rp.ntemp * BLK + 15) / 16 * 16; }
 // zy_global: z and y live in the slab as well (they are only ever indexed by their own row, so wave accesses are contiguous)
 inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp, bool zy_global = false) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;
-  return (res_stage_doubles_gb(rp) + 3L * pl.npad + rp.rext + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles_gb(pl, rp) + 3L * pl.npad + rp.rext + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
 }
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
