@@ -653,11 +653,11 @@ inline long res_stage_doubles_gb(const Plan &pl, const ResPlan &rp) { return gb_
 // zy_global: z and y live in the slab as well (they are only ever indexed by their own row, so wave accesses are contiguous)
 inline long lds_bytes_res_gb(const Plan &pl, const ResPlan &rp, bool zy_global = false) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;
-  return (res_stage_doubles_gb(pl, rp) + 3L * pl.npad + rp.rext + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles_gb(pl, rp) + 3L * pl.npad + rp.rext + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + sched_words) * 8L;
 }
 inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   const long sched_words = ((long)rp.g_seg.size() + rp.nw + 1 + 1) / 2 + 4;   // int32 segments kept in LDS, in doubles
-  return (res_stage_doubles(pl, rp) + 3L * pl.npad + rp.rext + 3L * pl.mpad + 16L * rp.nw + 16 + 32L * rp.nw + sched_words) * 8L;
+  return (res_stage_doubles(pl, rp) + 3L * pl.npad + rp.rext + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + sched_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {
