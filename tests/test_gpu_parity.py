@@ -626,3 +626,25 @@ def test_crossed_bounds_refuse_only_their_instance(built):
     qp.update_vectors(ls.q, ls.l, ls.u); qp.solve(); g3 = qp.get(); qp.close()
     assert np.array_equal(g3["status"], r3["status"]) and np.array_equal(g3["iters"], r3["iters"]) and (g3["status"] == 1).all()
     assert np.abs(g3["x"] - r3["x"]).max() <= 1e-6 * (1 + np.abs(r3["x"]).max())
+
+
+def test_handle_lifecycle_releases_device_memory(built):
+    """create / update / solve / destroy in a loop (QP handles and stage evaluators): free device memory returns to where it was"""
+    import torch
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    mdl, ls, _ = models.make_workload("quadrotor", 64, N=10)
+
+    def cycle(k):
+        for _ in range(k):
+            qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+            qp.keep_workspace(True)
+            qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); qp.get()
+            qp.update_vectors(ls.q, ls.l, ls.u); qp.solve(); qp.get(); qp.close()
+            ev = StageEvaluator(mdl); ev.close()
+
+    cycle(3); torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(40); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 40 create/destroy cycles" % ((free0 - free1) / 2**20)
