@@ -69,6 +69,7 @@ struct mpcqp_handle {
   bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
   bool zyg = false;             // ... with z, y in the slab instead of LDS (lifts workgroups per CU for long horizons)
   bool occ3 = false;            // ... its 168-VGPR instance (exactly 3 workgroups per CU fit in LDS), 8 blocks in flight
+  bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
@@ -289,6 +290,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
   h->lpt = !getenv("MPCQP_NO_LPT");
+  h->stream_pd8 = h->lds > 40 * 1024 && !getenv("MPCQP_PD4");   // streaming kernel: 8 blocks in flight when one QP per SIMD is all that fits
   {   // dispatch-hint buffers up front: nothing is allocated inside mpcqp_solve, so a solve can be captured in a HIP graph
     int rc;
     if ((rc = dalloc(h, &h->order[0], (size_t)batch)) || (rc = dalloc(h, &h->order[1], (size_t)batch))) return bail(rc);
@@ -413,7 +415,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
     void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, io.reuse != 0), dim3(h->batch), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
-  else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  else if (h->stream_pd8) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, s));
@@ -448,7 +450,7 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
     void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, false), dim3(count), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
-  else if (h->lds > 40 * 1024 && !getenv("MPCQP_PD4")) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
+  else if (h->stream_pd8) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   else hipLaunchKernelGGL(mpcqp_admm_kernel<4>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
   HIPCHK(hipGetLastError());
   if (m > 0) {
