@@ -32,12 +32,35 @@ def compare(tag, c, dims, variant, got, ref):
     # Tolerance-level divergence: same statuses, both sides pass OSQP's own termination test, the two eps = 1e-3 solutions differ
     # by less than that tolerance allows -- what two different factorisations of an ill-conditioned KKT system do over hundreds
     # of ADMM iterations (a 25-iteration check or an adaptive-rho decision flips).
-    if same_status and same_nan and ((err <= 2e-2 and ref["iters"].max() >= 200) or (err <= 1e-4 and (got["iters"] == ref["iters"]).all())):
+    # (an infeasibility certificate passing its eps_inf test one 25-iteration check earlier or later is the same kind of flip)
+    cert_flip = same_status and same_nan and err <= 1e-6 and np.abs(got["iters"] - ref["iters"]).max() <= 25 and \
+        np.isin(ref["status"][got["iters"] != ref["iters"]], (3, 4, 5, 6)).all()
+    if cert_flip or (same_status and same_nan and ((err <= 2e-2 and ref["iters"].max() >= 200) or (err <= 1e-4 and (got["iters"] == ref["iters"]).all()))):
         soft += 1
         print("tolerance-level %s case %d %s variant=%s iters %s/%s rel err %.2e" % (tag, c, dims, variant, got["iters"], ref["iters"], err))
     else:
         bad += 1
         print("MISMATCH %s case %d %s variant=%s status %s/%s iters %s/%s rel err %.2e" % (tag, c, dims, variant, got["status"], ref["status"], got["iters"], ref["iters"], err))
+
+
+def diagnose(ls, pat, variant):
+    """for a cold-solve mismatch: the longest prefix (in adaptive-rho intervals) on which GPU and oracle still agree tightly, and the dual
+    residual the next rho update divides by -- noise-level residuals there mean the two runs are different trajectories of the same algorithm"""
+    last = 0
+    for mi in (99, 199, 299, 399, 499, 999, 1999):
+        ref = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings(max_iter=mi))
+        qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, max_iter=mi)
+        qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+        fin = np.isfinite(ref["x"])
+        same = (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all() and np.array_equal(np.isfinite(got["x"]), fin)
+        err = np.abs(got["x"][fin] - ref["x"][fin]).max() / (1 + np.abs(ref["x"][fin]).max()) if fin.any() else 0.0
+        if not (same and err <= 1e-6):
+            break
+        last = mi; dual = (ref["dual_res"].min(), got["dual_res"].min())
+    if last:
+        print("    diagnosis (%s): agreement to 1e-6 through iteration %d; smallest dual residual there %.1e (oracle) / %.1e (GPU)" % (variant, last, dual[0], dual[1]))
+    else:
+        print("    diagnosis (%s): the runs differ before the first adaptive-rho update" % variant)
 
 
 for c in range(ncase):
@@ -67,7 +90,10 @@ for c in range(ncase):
         if variant != "stream":
             qp.keep_workspace(True)
         qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve()           # no start given: cold
+        bad0 = bad
         compare("cold", c, dims, variant, qp.get(), ref)
+        if bad > bad0 and variant is None:
+            diagnose(ls, pat, variant)
         if variant != "stream":
             qp.update_vectors(q2, l2, u2); qp.warm_start(x0, y0); qp.solve()
             compare("kept+warm", c, dims, variant, qp.get(), ref2)
