@@ -321,3 +321,64 @@ def test_maximum_sizes_on_device(built):
     assert np.array_equal(got["status"], want["status"]) and np.array_equal(got["iters"], want["iters"])
     ok = np.isfinite(want["x"])
     assert np.array_equal(np.isfinite(got["x"]), ok) and np.abs(got["x"][ok] - want["x"][ok]).max() <= 1e-6 * (1 + np.abs(want["x"][ok]).max())
+
+
+def _random_expression(rng, leaves, depth):
+    """a random smooth scalar expression over the tracer-supported operations, built so that every intermediate stays in a safe range"""
+    if depth == 0 or rng.random() < 0.15:
+        v = leaves[int(rng.integers(len(leaves)))]
+        return v if rng.random() < 0.8 else v * float(rng.uniform(-2, 2)) + float(rng.uniform(-1, 1))
+    op = rng.choice(["add", "sub", "mul", "div", "sin", "cos", "tanh", "exp", "log", "sqrt", "sq", "neg", "tan"])
+    a = _random_expression(rng, leaves, depth - 1)
+    if op in ("add", "sub", "mul", "div"):
+        b = _random_expression(rng, leaves, depth - 1)
+        if op == "add": return a + b
+        if op == "sub": return a - b
+        if op == "mul": return a * b
+        return a / (2.0 + np.tanh(b))                        # denominator in [1, 3]
+    if op == "sin": return np.sin(a)
+    if op == "cos": return np.cos(a)
+    if op == "tanh": return np.tanh(a)
+    if op == "exp": return np.exp(np.tanh(a))
+    if op == "log": return np.log(2.0 + np.tanh(a))
+    if op == "sqrt": return np.sqrt(2.0 + np.tanh(a))
+    if op == "sq": return a ** 2
+    if op == "tan": return np.tan(0.5 * np.tanh(a))
+    return -a
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_expressions_gradient_tape_and_mask(built, seed):
+    """randomised check of the symbolic reverse sweep and of the structural Hessian mask (codegen.gradient_tape / hessian_mask) against
+    complex-step differentiation of the traced value tape"""
+    nx, nu = 3, 2
+    def cost(s, u, r):
+        rng = np.random.default_rng(100 + seed)
+        leaves = [s[..., i] for i in range(nx)] + [u[..., i] for i in range(nu)] + [r[..., i] for i in range(nx)]
+        used = [leaves[i] for i in rng.choice(len(leaves), size=5, replace=False)]     # some inputs stay out: structural zeros
+        return _random_expression(rng, used, 4) + 0.5 * used[0] ** 2
+    L, G = codegen.trace_cost(cost, nx, nu, nx)
+    n = nx + nu + nx
+    mask = codegen.hessian_mask(G)
+    rng = np.random.default_rng(seed)
+    seen = np.zeros((n, n), bool)
+    for _ in range(3):
+        w = rng.normal(0, 0.7, n)
+        g = np.array([np.asarray(v, float) for v in G.evaluate(list(w))]).reshape(n)
+        cs = np.array([np.imag(L.evaluate(list(w + 1e-30j * np.eye(n)[i]))[0]) / 1e-30 for i in range(n)])
+        assert np.abs(g - cs).max() <= 1e-11 * (1 + np.abs(cs).max())
+        H = np.array([np.imag(np.array(G.evaluate(list(w + 1e-30j * np.eye(n)[i])), dtype=complex)) / 1e-30 for i in range(n)]).T
+        assert np.abs(H - H.T).max() <= 1e-9 * (1 + np.abs(H).max())
+        seen |= np.abs(H) > 0
+    assert not (seen & ~mask).any()                             # no nonzero outside the structural mask
+    if seed < 4:                                                # and the emitted functor (g++ build) reproduces value, gradient and Hessian
+        F = lambda s, u: np.stack([s[..., 0], s[..., 1], s[..., 2] + 0.1 * u[..., 0] * u[..., 1]], axis=-1)
+        lib = C.CDLL(codegen.build_host_library(codegen.trace(F, nx, nu, lcost=cost)))
+        lib.user_host_cost.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
+        w = rng.normal(0, 0.7, n); sv, uv, rv = w[:nx].copy(), w[nx:nx + nu].copy(), w[nx + nu:].copy()
+        val = np.zeros(1); gr = np.zeros(n); he = np.zeros((n, n))
+        lib.user_host_cost(sv.ctypes.data, uv.ctypes.data, rv.ctypes.data, 0, val.ctypes.data, gr.ctypes.data, he.ctypes.data)
+        g = np.array([np.asarray(v, float) for v in G.evaluate(list(w))]).reshape(n)
+        H = np.array([np.imag(np.array(G.evaluate(list(w + 1e-30j * np.eye(n)[i])), dtype=complex)) / 1e-30 for i in range(n)]).T
+        assert abs(val[0] - float(L.evaluate(list(w))[0])) <= 1e-13 * (1 + abs(val[0]))
+        assert np.abs(gr - g).max() <= 1e-12 * (1 + np.abs(g).max()) and np.abs(he - H).max() <= 1e-10 * (1 + np.abs(H).max())
