@@ -69,6 +69,7 @@ struct mpcqp_handle {
   bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
   bool zyg = false;             // ... with z, y in the slab instead of LDS (lifts workgroups per CU for long horizons)
   bool occ3 = false;            // ... its 168-VGPR instance (exactly 3 workgroups per CU fit in LDS), 8 blocks in flight
+  int res3 = 0;                 // LDS-resident 4-wave kernel: 3 or 4 workgroups per CU (168- / 128-VGPR instances) when the LDS footprint allows, else 0
   bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   ResPlan rplan; DevRes dres;
@@ -127,6 +128,8 @@ static const void *res_kernel_pick(const mpcqp_handle *h) {
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
   if (h->variant == 1) return (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
   if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
+  if (h->res3 == 4) return (const void *)mpcqp_res_kernel<4, 4, false, REUSE>;
+  if (h->res3 == 3) return (const void *)mpcqp_res_kernel<4, 3, false, REUSE>;
   return h->wide ? (const void *)mpcqp_res_kernel<4, 1, false, REUSE> : (const void *)mpcqp_res_kernel<4, 2, false, REUSE>;
 }
 static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) { return reuse ? res_kernel_pick<true>(h) : res_kernel_pick<false>(h); }
@@ -211,8 +214,11 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // LDS finish a QP soonest (double integrator x256: 1.12 ms vs 1.41 ms with one wave per QP; quadrotor N=20 x256:
       // 1.21 ms vs 1.96 ms with the factor streamed from HBM)
       const long cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      const long cap4 = (small_ok && l4 <= LDS_MAX) ? std::min<long>(LDS_MAX / l4, 2) : 0;
-      if (cap4 > 0 && (long)batch <= cus * cap4) want = 4;
+      // (workgroups of the LDS-resident 4-wave kernel per CU: by LDS, and by the register budget of its instances -- 128 / 168 / 256 VGPRs)
+      const long cap4 = (small_ok && l4 <= LDS_MAX) ? std::min<long>(LDS_MAX / l4, l4 <= 40 * 1024 ? 4 : l4 <= 53 * 1024 ? 3 : 2) : 0;
+      // (with three or four of them per CU they stay ahead of one wave per QP up to about three resident rounds: double integrator x2048 1.57 vs
+      // 1.81 ms, x4096 2.89 vs 2.76 ms)
+      if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
       else if (small_ok && l1 <= 40 * 1024) want = 1;
       else {
         if (small_ok && l4 <= 80 * 1024) want = 4;
@@ -238,6 +244,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
+      if (!h->gblocks && want == 4 && !getenv("MPCQP_NO_RES3")) h->res3 = need <= 40 * 1024 ? 4 : need <= 53 * 1024 ? 3 : 0;
       if (const char *pad = getenv("MPCQP_LDS_MIN")) h->lds = std::max<long>(h->lds, atol(pad));   // experiment: limit workgroups per CU
     }
     h->variant = want;

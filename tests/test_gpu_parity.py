@@ -673,3 +673,29 @@ def test_prefix_parity_where_adaptive_rho_is_noise_driven(built):
         _, A = ls.dense(b)
         Ax = A @ got["x"][b]
         assert np.maximum(np.maximum(ls.l[b] - Ax, Ax - ls.u[b]), 0.0).max() <= 1e-3 + 1e-3 * np.abs(Ax).max()
+
+
+@pytest.mark.parametrize("name,N,B,wgs", [("cartpole", 20, 48, 3), ("double_integrator", 30, 64, 3), ("double_integrator", 20, 40, 4)])
+def test_resident_kernel_at_three_and_four_workgroups_per_cu(built, monkeypatch, name, N, B, wgs):
+    """the LDS-resident 4-wave kernel's 168- and 128-VGPR instances (LDS footprint <= 53 / 40 KiB: three / four workgroups per CU)"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "res4")
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info()
+    assert info["variant"] == 4 and (40 * 1024 < info["lds_bytes"] <= 53 * 1024 if wgs == 3 else info["lds_bytes"] <= 40 * 1024)
+    qp.keep_workspace(True)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+    # and the kept-workspace entry of the same instances
+    from oracle import oracle as orc
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
+    st.solve(ls.P, ls.q, ls.A, ls.l, ls.u)
+    q2 = ls.q * 1.05
+    r2 = st.solve_vectors(q2, ls.l, ls.u)
+    qp.update_vectors(q2, ls.l, ls.u); qp.solve(); g2 = qp.get(); qp.close()
+    assert (g2["status"] == r2["status"]).all() and (g2["iters"] == r2["iters"]).all()
+    _close(g2, r2, "x")
