@@ -219,7 +219,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // (with three or four of them per CU they stay ahead of one wave per QP up to about three resident rounds: double integrator x2048 1.57 vs
       // 1.81 ms, x4096 2.89 vs 2.76 ms)
       if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
-      else if (small_ok && l1 <= 40 * 1024) want = 1;
+      // one wave per QP only where it puts more QPs on a CU than the 4-wave kernel has workgroups there (five against four at 28 KiB: +6 %;
+      // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
+      else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
       else {
         if (small_ok && l4 <= 80 * 1024) want = 4;
         else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
