@@ -69,6 +69,7 @@ struct mpcqp_handle {
   bool gblocks = false;         // multi-wave LDL' kernel with the factor blocks streamed from the HBM slab
   bool zyg = false;             // ... with z, y in the slab instead of LDS (lifts workgroups per CU for long horizons)
   bool occ3 = false;            // ... its 168-VGPR instance (exactly 3 workgroups per CU fit in LDS), 8 blocks in flight
+  bool res1x = false;           // one-wave kernel, 128-VGPR instance: more than eight QPs per CU when the LDS footprint allows (double integrator N=10: 12.1 -> 13.8 M QP/s)
   int res3 = 0;                 // LDS-resident 4-wave kernel: 3 or 4 workgroups per CU (168- / 128-VGPR instances) when the LDS footprint allows, else 0
   bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
@@ -126,7 +127,7 @@ static const void *res_kernel_pick(const mpcqp_handle *h) {
   if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
   if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
-  if (h->variant == 1) return (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
+  if (h->variant == 1) return h->res1x ? (const void *)mpcqp_res_kernel<1, 4, false, REUSE> : (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
   if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
   if (h->res3 == 4) return (const void *)mpcqp_res_kernel<4, 4, false, REUSE>;
   if (h->res3 == 3) return (const void *)mpcqp_res_kernel<4, 3, false, REUSE>;
@@ -246,6 +247,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
+      h->res1x = want == 1 && !h->gblocks && LDS_MAX / need > 8 && !getenv("MPCQP_NO_RES1X");
       if (!h->gblocks && want == 4 && !getenv("MPCQP_NO_RES3")) h->res3 = need <= 40 * 1024 ? 4 : need <= 53 * 1024 ? 3 : 0;
       if (const char *pad = getenv("MPCQP_LDS_MIN")) h->lds = std::max<long>(h->lds, atol(pad));   // experiment: limit workgroups per CU
     }

@@ -675,6 +675,20 @@ def test_prefix_parity_where_adaptive_rho_is_noise_driven(built):
         assert np.maximum(np.maximum(ls.l[b] - Ax, Ax - ls.u[b]), 0.0).max() <= 1e-3 + 1e-3 * np.abs(Ax).max()
 
 
+def test_one_wave_kernel_beyond_eight_per_cu(built):
+    """the 128-VGPR instance of the one-wave kernel (LDS footprint below 17.7 KiB: more than eight QPs per CU)"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("double_integrator", 4000, N=10)      # past the batch-aware rule's three resident rounds
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info()
+    assert info["variant"] == 1 and 160 * 1024 // info["lds_bytes"] > 8
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+
+
 @pytest.mark.parametrize("name,N,B,wgs", [("cartpole", 20, 48, 3), ("double_integrator", 30, 64, 3), ("double_integrator", 20, 40, 4)])
 def test_resident_kernel_at_three_and_four_workgroups_per_cu(built, monkeypatch, name, N, B, wgs):
     """the LDS-resident 4-wave kernel's 168- and 128-VGPR instances (LDS footprint <= 53 / 40 KiB: three / four workgroups per CU)"""
