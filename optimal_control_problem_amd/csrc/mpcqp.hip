@@ -129,6 +129,7 @@ static const void *res_kernel_pick(const mpcqp_handle *h) {
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
   if (h->variant == 1) return h->res1x ? (const void *)mpcqp_res_kernel<1, 4, false, REUSE> : (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
   if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
+  if (h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, false, REUSE>;
   if (h->res3 == 4) return (const void *)mpcqp_res_kernel<4, 4, false, REUSE>;
   if (h->res3 == 3) return (const void *)mpcqp_res_kernel<4, 3, false, REUSE>;
   return h->wide ? (const void *)mpcqp_res_kernel<4, 1, false, REUSE> : (const void *)mpcqp_res_kernel<4, 2, false, REUSE>;
@@ -195,6 +196,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       std::string v(e);
       if (v == "stream") want = 0; else if (v == "res1") want = 1; else if (v == "res4") want = 4; else if (v == "res8") want = 8;
       else if (v == "gres4") { want = 4; h->gblocks = true; }
+      else if (v == "res2") want = 2;
     }
     // candidate plans of the multi-wave kernels: ELL chunk widths padded to multiples of 4 (fewer load batches per chunk)
     // and the stage chain eliminated from both ends (two concurrent half-length chains)
@@ -219,7 +221,16 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const long cap4 = (small_ok && l4 <= LDS_MAX) ? std::min<long>(LDS_MAX / l4, l4 <= 40 * 1024 ? 4 : l4 <= 53 * 1024 ? 3 : 2) : 0;
       // (with three or four of them per CU they stay ahead of one wave per QP up to about three resident rounds: double integrator x2048 1.57 vs
       // 1.81 ms, x4096 2.89 vs 2.76 ms)
-      if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
+      // two waves per QP (168-VGPR instance: up to six per CU): the two half chains of the twisted order each get a wave and nothing idles in
+      // the chain phases.  Taken where it fits more QPs per CU than the 4-wave kernel and at most one fewer than one wave per QP would:
+      // double integrator N=20 (28 KiB, five per CU) 1.87 M QP/s against 1.55 M with one wave and 1.46 M with four; at 21-23 KiB +4...8 %
+      // over one wave; below 15 KiB one wave per QP (11-13 per CU) wins, at 34 KiB and above the 4-wave kernel; same latency as the 4-wave
+      // kernel on a batch of 64-1024
+      const ResPlan r2 = build_res_plan(p4, 2);
+      const long l2 = lds_bytes_res(p4, r2);
+      const long q1 = small_ok && l1 <= LDS_MAX ? LDS_MAX / l1 : 0, q2 = small_ok && l2 <= 40 * 1024 ? std::min<long>(LDS_MAX / l2, 6) : 0;
+      if (q2 > cap4 && q2 + 1 >= q1 && !getenv("MPCQP_NO_RES2")) want = 2;
+      else if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
       // one wave per QP only where it puts more QPs on a CU than the 4-wave kernel has workgroups there (five against four at 28 KiB: +6 %;
       // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
       else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
