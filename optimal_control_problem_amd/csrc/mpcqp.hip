@@ -187,8 +187,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   const Plan &pl = h->plan;
   h->wl = ws_layout(pl);
   h->lds = lds_bytes(pl);
-  // Variant: keep the factor in LDS when it fits. Small problems take one wave per QP (several QPs per CU);
-  // larger ones that still fit take four waves per QP. MPCQP_VARIANT=stream|res1|res4|res8 overrides.
+  // Kernel shape, from measured rules (profiles/r01_variant_grid.txt): factor in LDS with one, two or four waves per
+  // QP while enough QPs fit a CU, else the factor streamed from the HBM slab.  MPCQP_VARIANT=stream|res1|res2|res4|res8|gres4 overrides.
   {
     const long LDS_MAX = 160 * 1024;
     int want = -1;
@@ -219,8 +219,6 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const long cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       // (workgroups of the LDS-resident 4-wave kernel per CU: by LDS, and by the register budget of its instances -- 128 / 168 / 256 VGPRs)
       const long cap4 = (small_ok && l4 <= LDS_MAX) ? std::min<long>(LDS_MAX / l4, l4 <= 40 * 1024 ? 4 : l4 <= 53 * 1024 ? 3 : 2) : 0;
-      // (with three or four of them per CU they stay ahead of one wave per QP up to about three resident rounds: double integrator x2048 1.57 vs
-      // 1.81 ms, x4096 2.89 vs 2.76 ms)
       // two waves per QP (168-VGPR instance: up to six per CU): the two half chains of the twisted order each get a wave and nothing idles in
       // the chain phases.  Taken where it fits more QPs per CU than the 4-wave kernel and at most one fewer than one wave per QP would:
       // double integrator N=20 (28 KiB, five per CU) 1.87 M QP/s against 1.55 M with one wave and 1.46 M with four; at 21-23 KiB +4...8 %
@@ -230,6 +228,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const long l2 = lds_bytes_res(p4, r2);
       const long q1 = small_ok && l1 <= LDS_MAX ? LDS_MAX / l1 : 0, q2 = small_ok && l2 <= 40 * 1024 ? std::min<long>(LDS_MAX / l2, 6) : 0;
       if (q2 > cap4 && q2 + 1 >= q1 && !getenv("MPCQP_NO_RES2")) want = 2;
+      // the latency regime above; with three or four 4-wave workgroups per CU they stay ahead of one wave per QP up to about three resident
+      // rounds (double integrator x2048 1.57 vs 1.81 ms, x4096 2.89 vs 2.76 ms)
       else if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
       // one wave per QP only where it puts more QPs on a CU than the 4-wave kernel has workgroups there (five against four at 28 KiB: +6 %;
       // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
