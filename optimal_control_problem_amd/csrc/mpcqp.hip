@@ -124,6 +124,7 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->gblocks && h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, true, REUSE>;
   if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
   if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
   if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
@@ -197,6 +198,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       if (v == "stream") want = 0; else if (v == "res1") want = 1; else if (v == "res4") want = 4; else if (v == "res8") want = 8;
       else if (v == "gres4") { want = 4; h->gblocks = true; }
       else if (v == "res2") want = 2;
+      else if (v == "gres2") { want = 2; h->gblocks = true; }
     }
     // candidate plans of the multi-wave kernels: ELL chunk widths padded to multiples of 4 (fewer load batches per chunk)
     // and the stage chain eliminated from both ends (two concurrent half-length chains)
@@ -236,6 +238,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
       else {
         if (small_ok && l4 <= 80 * 1024) want = 4;
+        // factor streamed from the slab; two waves per QP (168-VGPR instance, six workgroups per CU instead of four) while six fit the LDS:
+        // double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB and above four waves win
+        else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) { want = 2; h->gblocks = true; }
         else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
         else want = 0;
       }

@@ -306,7 +306,7 @@ def test_full_size_quadrotor_properties(built):
 
 
 # ---------------------------------------------------------------------------------------------- kernel variants
-@pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "res8", "gres4"])
+@pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "res8", "gres4", "gres2"])
 @pytest.mark.parametrize("name,batch,N", [("double_integrator", 40, 20), ("quadrotor", 24, 20), ("cartpole", 6, 30)])
 def test_kernel_variants_vs_oracle(built, monkeypatch, variant, name, batch, N):
     """every kernel family (HBM-streamed factor; LDS-resident block LDL' with 1 / 4 / 8 waves per QP) against the oracle"""
@@ -314,7 +314,7 @@ def test_kernel_variants_vs_oracle(built, monkeypatch, variant, name, batch, N):
     monkeypatch.setenv("MPCQP_VARIANT", variant)
     mdl, ls, _ = models.make_workload(name, batch, N=N)
     qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
-    assert qp.plan_info()["variant"] == {"stream": 0, "res1": 1, "res2": 2, "res4": 4, "res8": 8, "gres4": 104}[variant]
+    assert qp.plan_info()["variant"] == {"stream": 0, "res1": 1, "res2": 2, "res4": 4, "res8": 8, "gres4": 104, "gres2": 102}[variant]
     qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
     ref = problems.oracle_solve(ls)
     assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
@@ -322,7 +322,7 @@ def test_kernel_variants_vs_oracle(built, monkeypatch, variant, name, batch, N):
         _close(got, ref, k)
 
 
-@pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "gres4"])
+@pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "gres4", "gres2"])
 def test_kernel_variants_hard_cases(built, monkeypatch, variant):
     """adaptive-rho refactorisation, infeasibility certificates, max-iter exit, non-convex rejection per kernel family"""
     monkeypatch.setenv("MPCQP_VARIANT", variant)

@@ -80,7 +80,7 @@ for c in range(ncase):
     x0 = np.where(ok0[:, None], ref["x"], 0.0); y0 = np.where(ok0[:, None], ref["y"], 0.0)
     st = orc.State(pat, B, orc.default_settings(warm_start=1)); st.solve(ls.P, ls.q, ls.A, ls.l, ls.u)
     ref2 = st.solve_vectors(q2, l2, u2, x0=x0, y0=y0)
-    for variant in (None, "res1", "res2", "res4", "gres4", "stream"):
+    for variant in (None, "res1", "res2", "res4", "gres4", "gres2", "stream"):
         if variant: os.environ["MPCQP_VARIANT"] = variant
         else: os.environ.pop("MPCQP_VARIANT", None)
         try:
