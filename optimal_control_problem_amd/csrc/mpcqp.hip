@@ -237,9 +237,12 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
       else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
       else {
+        // LDS-resident 4-wave kernel while two fit a CU.  (Against it the two-wave global-block kernel below is +8...11 % on double integrator
+        // N=40 / 50 and +3 % on cart-pole N=30, but -6 % on cart-pole N=25 and -3 % on quadrotor N=7: no clean rule, so the resident kernel stays)
         if (small_ok && l4 <= 80 * 1024) want = 4;
-        // factor streamed from the slab; two waves per QP (168-VGPR instance, six workgroups per CU instead of four) while six fit the LDS:
-        // double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB and above four waves win
+        // factor streamed from the slab, two waves per QP (168-VGPR instance, six workgroups per CU) while six fit the LDS: ahead of four waves x
+        // four workgroups there (double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB
+        // and above four waves win)
         else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) { want = 2; h->gblocks = true; }
         else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
         else want = 0;
