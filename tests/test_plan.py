@@ -88,7 +88,7 @@ def _run_res(ls, nw, b=0, seed=0):
     return dict(ntemp=info[0] % 100, ordering=info[0] // 100, nphase=info[1], lds=info[2], barriers=info[3] % 1000, segments=info[3] // 1000)
 
 
-@pytest.mark.parametrize("nw", [1, 4, 8])
+@pytest.mark.parametrize("nw", [1, 2, 4, 8])
 @pytest.mark.parametrize("name,N", [("double_integrator", 20), ("quadrotor", 20), ("cartpole", 30)])
 def test_res_plan_stage_models(built, name, N, nw):
     mdl, ls, _ = models.make_workload(name, 1, N=N)
@@ -105,7 +105,7 @@ def test_res_plan_stage_models(built, name, N, nw):
 @pytest.mark.parametrize("seed", range(3))
 def test_res_plan_random(built, seed):
     ls = problems.random_qp(20 + 13 * seed, 30 + 11 * seed, seed, density=0.15)
-    for nw in (1, 4):
+    for nw in (1, 2, 4):
         _run_res(ls, nw, seed=seed)
 
 
@@ -119,7 +119,7 @@ def test_res_plan_rejects_indefinite(built):
                               _p(rhs), _p(sol), _p(info)) == 2
 
 
-@pytest.mark.parametrize("nw", [4, 8])
+@pytest.mark.parametrize("nw", [2, 4, 8])
 def test_res_plan_twisted_ordering(built, nw):
     """two-sided elimination of the stage chain (ordering 2, passed as nw + 200): same block count and LDS footprint,
     roughly half the phases, still hazard-free and exact"""
@@ -127,7 +127,7 @@ def test_res_plan_twisted_ordering(built, nw):
     base = _run_res(ls, nw)
     tw = _run_res(ls, nw + 200)
     sp = _run_res(ls, nw + 200 + 10000)                          # the same with the arrow run split over the waves (global-block plans)
-    if nw == 4:                                                    # 20 arrow ops >= 4 * nw: split; with 8 waves the run stays whole
+    if nw in (2, 4):                                               # 20 arrow ops >= 4 * nw: split; with 8 waves the run stays whole
         assert sp["nphase"] == tw["nphase"] + 1 and sp["barriers"] <= tw["barriers"] + 2
     else:
         assert sp["nphase"] == tw["nphase"]
@@ -149,7 +149,7 @@ def test_slab_layout_and_schedule_bounds(built, name, N):
     mdl, ls, _ = models.make_workload(name, 1, N=N)
     for force in (-1, 0, 1, 2):
         assert L.plan_check_layout(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), force) == 0
-        for nw in (1, 4, 8):
+        for nw in (1, 2, 4, 8):
             info = np.zeros(8, np.int64)
             for split in (0, 10000):
                 assert L.plan_check_segments(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), nw + 100 * (force + 1) + split, _p(info)) == 0
