@@ -76,6 +76,13 @@ def main():
 
     if args.variant:
         os.environ["MPCQP_VARIANT"] = args.variant
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, before this process has
+        # imported torch or touched the GPU (the driver's torch.distributed.run launch sets WORLD_SIZE and skips this)
+        from optimal_control_problem_amd import sharding
+        raise SystemExit(sharding.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
     import torch
     from optimal_control_problem_amd import models, sharding
     from optimal_control_problem_amd.batch_qp import BatchQP
@@ -106,6 +113,10 @@ def main():
     if args.force_iters:
         kw.update(max_iter=args.force_iters, eps_abs=0.0, eps_rel=0.0, eps_prim_inf=0.0, eps_dual_inf=0.0, adaptive_rho=0)
     qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, **kw)
+    # `value` is measured with the instances handed to workgroups in batch order.  The longest-first dispatch hint
+    # (mpcqp_set_dispatch_hint, on by default in the library) predicts from the previous solve of the same handle; this
+    # loop re-solves one batch, which would make that prediction exact, so it is reported separately (with_dispatch_hint).
+    qp.set_dispatch_hint(False)
     pinfo = qp.plan_info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -163,7 +174,7 @@ def main():
             "config": {"workload": "%s nx=%d nu=%d horizon=%d, reference formulation n=%d m=%d, batch=%d per GPU, "
                                    "eps_abs=eps_rel=1e-3, cold start" % (mdl.name, mdl.nx, mdl.nu, N, ls.n, ls.m, batch),
                        "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "dispatch": "longest-first by the previous solve's ADMM iteration counts (scheduling hint, results unchanged)"},
+                       "dispatch": "batch order (the longest-first hint from the previous solve's iteration counts is off for `value`; see with_dispatch_hint)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # the same launch priced on its measured HBM traffic instead of the algorithmic bytes
@@ -186,18 +197,18 @@ def main():
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
         if world == 1 and not args.force_iters and not args.no_extras:
-            # the same step with the dispatch hint off (instances handed to workgroups in batch order, as a first solve on a
-            # fresh handle does): separates the kernel from the scheduling gain.  `value` is the default behaviour (hint on).
-            qp.set_dispatch_hint(False)
+            # the same step with the library's default dispatch hint on: instances ordered longest-first by the previous solve's
+            # ADMM iteration counts.  On this repeated batch the prediction is exact, so this is the hint's upper bound.
+            qp.set_dispatch_hint(True)
             for _ in range(2):
                 step()
             torch.cuda.synchronize(); tn = time.perf_counter()
             for _ in range(5):
                 step()
             torch.cuda.synchronize(); tn = (time.perf_counter() - tn) / 5
-            out["in_order_dispatch"] = {"value": batch / tn, "unit": "QP solves/s", "ms_per_step": tn * 1e3,
-                                        "note": "mpcqp_set_dispatch_hint(h, 0): no longest-first ordering from the previous solve's iteration counts"}
-            qp.set_dispatch_hint(True)
+            out["with_dispatch_hint"] = {"value": batch / tn, "unit": "QP solves/s", "ms_per_step": tn * 1e3,
+                                         "note": "mpcqp_set_dispatch_hint(h, 1) (library default): longest-first from the previous solve's iteration counts; exact predictor on a repeated batch"}
+            qp.set_dispatch_hint(False)
             # the same step with the boundary handing over HOST buffers (what a CuCaQP-style caller does: pageable inputs in,
             # x / status / iters out): H2D + kernel + D2H per step.  Reported beside `value`, never as `value`.
             hx = np.empty((batch, ls.n)); hst = np.empty(batch, np.int32); hit = np.empty(batch, np.int32)
@@ -237,21 +248,37 @@ def main():
             pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
             st = orc.default_settings()
             pat.solve(ls.P[:64], ls.q[:64], ls.A[:64], ls.l[:64], ls.u[:64], st, nthreads=cores)  # warm the threads
-            reps = 0; tc = 0.0
-            while tc * cores < 12.0 and reps < 50:       # ~10-30 s of CPU work in total
+            times = []
+            while (sum(times) * cores < 12.0 or len(times) < 10) and len(times) < 50:       # >= 10 repetitions, ~10-30 s of CPU work in total
                 t1 = time.perf_counter()
                 ref = pat.solve(ls.P[:ns], ls.q[:ns], ls.A[:ns], ls.l[:ns], ls.u[:ns], st, nthreads=cores)
-                tc += time.perf_counter() - t1; reps += 1
-            tc /= reps
+                times.append(time.perf_counter() - t1)
+            reps = len(times); tc = float(np.median(times))
             xg = ox[:ns].cpu().numpy()
             fin = np.isfinite(ref["x"])
             out["cpu_baseline"] = {"value": ns / tc, "unit": "QP solves/s", "cores": cores, "kind": "port",
                                    "sample": "first %d QPs of the same batch, OpenMP over instances, sparse LDL' per QP "
-                                             "(symbolic analysis shared), %d repetitions, %.2f s wall each, logical CPUs on the box %d" % (ns, reps, tc, os.cpu_count() or 0)}
+                                             "(symbolic analysis shared), median of %d repetitions, %.2f s wall each, logical CPUs on the box %d" % (ns, reps, tc, os.cpu_count() or 0)}
             # one host thread, one QP at a time -- how the reference itself runs (SURVEY.md section 8d baseline (a))
             n1 = min(ns, 512)
             t1 = time.perf_counter(); pat.solve(ls.P[:n1], ls.q[:n1], ls.A[:n1], ls.l[:n1], ls.u[:n1], st, nthreads=1); t1 = time.perf_counter() - t1
             out["cpu_baseline"]["single_thread"] = {"value": n1 / t1, "unit": "QP solves/s", "cores": 1, "sample": "first %d QPs, %.2f s" % (n1, t1)}
+            # a real OSQP on this box, if there is one: the reference's true CPU path, one QP at a time with a fresh
+            # setup each, and a pin for the oracle.  Absent from this image; the probe result is recorded either way.
+            from oracle import osqp_probe
+            found = osqp_probe.find()
+            out["cpu_baseline"]["osqp_probe"] = {"python_module": found["version"] if found["python"] is not None else None, "libosqp": found["libs"]}
+            if found["python"] is not None:
+                try:
+                    k = min(ns, 256)
+                    r = osqp_probe.solve_batch(found["python"], ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P, ls.q, ls.A, ls.l, ls.u, k)
+                    fin2 = np.isfinite(ref["x"][:k]).all(axis=1) & np.isfinite(r["x"]).all(axis=1)
+                    out["cpu_baseline"]["osqp"] = {"value": k / r["seconds"], "unit": "QP solves/s", "cores": 1, "kind": "osqp",
+                                                   "sample": "first %d QPs, fresh osqp setup per QP, settings of SQPOptimizationSolver.cpp:81-85" % k,
+                                                   "mean_iters": float(r["iters"].mean()),
+                                                   "max_abs_x_diff_vs_oracle": float(np.abs(r["x"][fin2] - ref["x"][:k][fin2]).max()) if fin2.any() else None}
+                except Exception as e:        # an unexpected binding version must not take the bench line down
+                    out["cpu_baseline"]["osqp"] = {"error": repr(e)}
             out["parity"] = {"max_abs_x_err_vs_oracle": float(np.abs(xg[fin] - ref["x"][fin]).max()),
                              "iters_equal": bool((iters[:ns] == ref["iters"]).all()),
                              "status_equal": bool((status[:ns] == ref["status"]).all())}

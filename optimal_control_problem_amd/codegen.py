@@ -576,25 +576,34 @@ void user_host_path(const double *s, const double *u, double *out, double *jac) 
 '''
 
 
+def _private_dir(d):
+    """d exists, belongs to this user and nobody else may write to it (a library found there is dlopen'ed)"""
+    st = os.stat(d)
+    return st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+
+
 def cache_dir():
-    """MPCQP_CACHE_DIR, else <package>/_gen, else a per-user directory under the system temp dir (read-only installs)"""
+    """MPCQP_CACHE_DIR, else <package>/_gen, else a per-user 0700 directory under the system temp dir (read-only installs).
+    Libraries in it are loaded without a rebuild, so a directory another user could have prepared is never used."""
     import tempfile
     for d in (os.environ.get("MPCQP_CACHE_DIR"), os.path.join(_HERE, "_gen"),
               os.path.join(tempfile.gettempdir(), "mpcqp_gen_%d" % os.getuid())):
         if not d:
             continue
         try:
-            os.makedirs(d, exist_ok=True)
-            if os.access(d, os.W_OK):
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            if os.access(d, os.W_OK) and _private_dir(d):
                 return d
         except OSError:
             pass
-    raise RuntimeError("no writable directory for generated dynamics libraries (set MPCQP_CACHE_DIR)")
+    raise RuntimeError("no private writable directory for generated dynamics libraries (set MPCQP_CACHE_DIR)")
 
 
 def _build(src_text, suffix, cmd_prefix):
-    key = hashlib.sha256((src_text + open(os.path.join(CSRC, "stage_kernels.hpp")).read() +
-                          open(os.path.join(CSRC, "stage_models.hpp")).read()).encode()).hexdigest()[:20]
+    # the key covers everything the library is compiled from: the generated source, every header it includes and the command
+    deps = "".join(open(os.path.join(CSRC, f)).read() for f in ("stage_kernels.hpp", "stage_models.hpp", "common.hpp"))
+    deps += open(os.path.join(_HERE, "..", "include", "mpcqp.h")).read()
+    key = hashlib.sha256((src_text + deps + " ".join(cmd_prefix)).encode()).hexdigest()[:20]
     base = os.path.join(cache_dir(), "user_%s_%s" % (suffix, key))
     so, src = base + ".so", base + (".hip" if suffix == "dev" else ".cpp")
     if not os.path.exists(so):

@@ -10,6 +10,7 @@
 // overloads of the reference are compiled only where those headers exist (they do not in this image).
 // One object may hold a batch of QPs of one sparsity (value arrays instance-major); batch = 1 is the drop-in case.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <iostream>
 #include <vector>
@@ -93,13 +94,13 @@ class CuCaQP {
   // skips the setup); a matrix update falls back to a full setup at the next solve().
   bool updateHessianMatrix(const CscView &P) {
     if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
-    vectorsOnly_ = false; matricesDirty_ = true;
-    return setHessianMatrix(P);
+    const bool same = samePattern(P, Pp_, Pi_);
+    return setHessianMatrix(P) && updateMatrix(same, "Hessian");
   }
   bool updateLinearConstraintsMatrix(const CscView &A) {
     if (!isInitialized_) { std::cerr << "Error: Solver not initialized. Call initSolver() first." << std::endl; return false; }
-    vectorsOnly_ = false; matricesDirty_ = true;
-    return setLinearConstraintsMatrix(A);
+    const bool same = samePattern(A, Ap_, Ai_);
+    return setLinearConstraintsMatrix(A) && updateMatrix(same, "Constraint");
   }
   bool updateGradient(const double *q, int size) { return updateVector(setGradient(q, size)); }
   bool updateLowerBound(const double *l, int size) { return updateVector(setLowerBound(l, size)); }
@@ -182,6 +183,16 @@ class CuCaQP {
     bool changed = ncp != cp || nri != ri;
     cp.swap(ncp); ri.swap(nri);
     return changed;
+  }
+  // a matrix update keeps the plan: another sparsity pattern is stored but refused here and needs initSolver() (osqp_update_data_mat
+  // has the same rule)
+  static bool samePattern(const CscView &M, const std::vector<int> &cp, const std::vector<int> &ri) {
+    return (int)cp.size() == M.cols + 1 && std::equal(cp.begin(), cp.end(), M.colptr) && (int)ri.size() == M.colptr[M.cols] && std::equal(ri.begin(), ri.end(), M.rowidx);
+  }
+  bool updateMatrix(bool same, const char *what) {
+    if (!same) { isInitialized_ = false; std::cerr << "Error: " << what << " sparsity pattern changed. Call initSolver() again." << std::endl; return false; }
+    vectorsOnly_ = false; matricesDirty_ = true;
+    return true;
   }
   void clearSolver() { if (handle_) { mpcqp_destroy(handle_); handle_ = nullptr; } isInitialized_ = false; }
   bool updateVector(bool stored) {

@@ -4,7 +4,9 @@
 //     mpcqp_stage_eval (getLocalSystem, :100-120) -> mpcqp_update(device) + mpcqp_solve (setSystem/initSolver/solve, :155-157)
 //     -> mpcqp_stage_step (result.x += alpha * solution[pSize:], :171-177) -> mpcqp_stage_merit (objective, :180-181).
 // Same quirks as the reference: a fixed number of iterations (step_num), no line search, the iterate persists across calls
-// and starts at zero, arg.x0 is ignored.  Header-only; needs the HIP runtime for the device buffers (hipMalloc / hipMemcpy).
+// and starts at zero, arg.x0 is ignored.  Opt-in extension: setTolerance(t) adds a convergence stop that the reference has
+// only under `verbose` (:183-197) -- the loop ends after the first iteration in which every instance moved by less than t
+// (max-norm of alpha * dx, mpcqp_stage_step's step_max).  Header-only; needs the HIP runtime for the device buffers (hipMalloc / hipMemcpy).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -65,6 +67,9 @@ class StageSQP {
     hip(hipMemcpy(x_, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice));
   }
 
+  void setTolerance(double tol) { tol_ = tol; }                   // 0 (default) = the reference's fixed iteration count
+  int iterationsDone() const { return iterationsDone_; }
+
   Result getOptimalSolution(const Arg &arg) {
     const size_t B = batch_;
     need(arg.lbx.size(), B * nvar(), "lbx"); need(arg.ubx.size(), B * nvar(), "ubx");
@@ -75,7 +80,15 @@ class StageSQP {
       check(mpcqp_update(qp_, dP_, nnzP(), dq_, n(), dA_, nnzA(), dl_, m(), du_, m(), MPCQP_MEM_DEVICE), "mpcqp_update");
       check(mpcqp_solve(qp_, nullptr), "mpcqp_solve");
       check(mpcqp_get(qp_, dw_, nullptr, nullptr, nullptr, nullptr, nullptr, MPCQP_MEM_DEVICE), "mpcqp_get");
-      check(mpcqp_stage_step(ocp_, batch_, alpha_, dw_, x_, nullptr, nullptr, nullptr), "mpcqp_stage_step");
+      check(mpcqp_stage_step(ocp_, batch_, alpha_, dw_, x_, tol_ > 0.0 ? g_ : nullptr, nullptr, nullptr), "mpcqp_stage_step");
+      iterationsDone_ = i + 1;
+      if (tol_ > 0.0) {                                           // one vector of step norms back to the host per iteration
+        stepMax_.resize(B);
+        hip(hipMemcpy(stepMax_.data(), g_, B * sizeof(double), hipMemcpyDeviceToHost));
+        double worst = 0.0;
+        for (double v : stepMax_) if (v > worst) worst = v;
+        if (worst < tol_) break;
+      }
     }
     check(mpcqp_stage_merit(ocp_, batch_, p_, x_, f_, g_, nullptr), "mpcqp_stage_merit");
     Result r; r.x.resize(B * nvar()); r.f.resize(B); violation_.resize(B);
@@ -95,7 +108,8 @@ class StageSQP {
   double *dalloc(size_t count) { double *p = nullptr; hip(hipMalloc(&p, (count ? count : 1) * sizeof(double))); bufs_.push_back(p); return p; }
   void up(double *dst, const std::vector<double> &src) { if (!src.empty()) hip(hipMemcpy(dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice)); }
 
-  int batch_, stepNum_; double alpha_;
+  int batch_, stepNum_; double alpha_; double tol_ = 0.0; int iterationsDone_ = 0;
+  std::vector<double> stepMax_;
   int dims_[8] = {0};
   mpcqp_stage *ocp_ = nullptr; mpcqp_handle *qp_ = nullptr;
   double *x_ = nullptr, *dP_ = nullptr, *dq_ = nullptr, *dA_ = nullptr, *dl_ = nullptr, *du_ = nullptr, *dw_ = nullptr, *f_ = nullptr, *g_ = nullptr;

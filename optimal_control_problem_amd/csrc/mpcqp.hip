@@ -27,6 +27,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -310,17 +312,25 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
 #endif
 #undef UP
   h->wide = h->variant == 4 && h->lds > 80 * 1024;
+  h->stream_pd8 = h->lds > 40 * 1024 && !getenv("MPCQP_PD4");   // streaming kernel: 8 blocks in flight when one QP per SIMD is all that fits
   if (h->lds > 48 * 1024) {
+    // MaxDynamicSharedMemorySize is a property of the kernel function, shared by every handle that launches it: keep a running
+    // maximum per function so that a later handle with a smaller footprint never lowers the limit under an earlier one
+    static std::mutex mu; static std::map<std::pair<const void *, int>, long> limit;   // (function, device)
     const void *fns[2] = {res_kernel_of(h, false), res_kernel_of(h, true)};
-    if (h->variant == 0) fns[0] = fns[1] = h->lds > 40 * 1024 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>;
-    for (const void *fn : fns)
+    if (h->variant == 0) fns[0] = fns[1] = h->stream_pd8 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const void *fn : fns) {
+      long &cur = limit[{fn, h->device}];
+      if (h->lds <= cur) continue;
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
         return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
+      cur = h->lds;
+    }
   }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
   h->lpt = !getenv("MPCQP_NO_LPT");
-  h->stream_pd8 = h->lds > 40 * 1024 && !getenv("MPCQP_PD4");   // streaming kernel: 8 blocks in flight when one QP per SIMD is all that fits
   {   // dispatch-hint buffers up front: nothing is allocated inside mpcqp_solve, so a solve can be captured in a HIP graph
     int rc;
     if ((rc = dalloc(h, &h->order[0], (size_t)batch)) || (rc = dalloc(h, &h->order[1], (size_t)batch))) return bail(rc);

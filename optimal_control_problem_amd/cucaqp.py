@@ -38,6 +38,8 @@ class CuCaQP:
         self._result = None
         self._start = None
         self._rho0 = None
+        self._kept = False
+        self._vectors_dirty = self._matrices_dirty = self._solved_once = False
 
     # -- dimensions (CuCaQP.cpp:23-41)
     def setDimension(self, numOfVariables, numOfConstraints):
@@ -144,23 +146,38 @@ class CuCaQP:
         self.upperBound = v
         return True
 
-    # -- the reference's private update* members (CuCaQP.cpp:106-161; never called there).  Here they work: vectors go through
-    # the kept workspace (mpcqp_update_vectors: scaling, factorisation and rho stay), matrices force a full setup.
+    # -- the reference's private update* members (CuCaQP.cpp:106-161; never called there).  Here they work, with the same
+    # bookkeeping as the C++ facade (cpp/CuCaQP.hpp: vectorsOnly_ / matricesDirty_ / solvedOnce_): the next solve() sends the new
+    # data -- vectors alone through the kept workspace (mpcqp_update_vectors: scaling, factorisation and rho stay) when a solve
+    # has happened on it and the matrices are unchanged, everything through a full mpcqp_update otherwise.  A matrix with another
+    # sparsity pattern needs a new plan: the updater refuses it and asks for initSolver().
+    def _same_pattern(self, old, new):
+        return old is not None and np.array_equal(old[0], new[0]) and np.array_equal(old[1], new[1])
+
+    def _update_mat(self, setter, attr, value, what):
+        if not self.isInitialized_:
+            return _err("Solver not initialized. Call initSolver() first.")          # CuCaQP.cpp:107-110 and siblings
+        old = getattr(self, attr)
+        if not setter(value):
+            return False
+        if not self._same_pattern(old, getattr(self, attr)):
+            self.isInitialized_ = False
+            return _err("%s sparsity pattern changed. Call initSolver() again." % what)
+        self._matrices_dirty = True
+        return True
+
     def updateHessianMatrix(self, hessian):
-        self._vectors_only = False
-        return self.setHessianMatrix(hessian)
+        return self._update_mat(self.setHessianMatrix, "_P", hessian, "Hessian")
 
     def updateLinearConstraintsMatrix(self, A):
-        self._vectors_only = False
-        return self.setLinearConstraintsMatrix(A)
+        return self._update_mat(self.setLinearConstraintsMatrix, "_A", A, "Constraint")
 
     def _update_vec(self, setter, v):
         if not self.isInitialized_:
-            return _err("Solver not initialized. Call initSolver() first.")          # CuCaQP.cpp:107-110 and siblings
+            return _err("Solver not initialized. Call initSolver() first.")          # CuCaQP.cpp:118-121 and siblings
         if not setter(v):
             return False
-        if self._qp is not None and self._result is not None and getattr(self, "_kept", False):
-            self._vectors_only = True
+        self._vectors_dirty = True
         return True
 
     def updateGradient(self, q):
@@ -176,7 +193,7 @@ class CuCaQP:
         """[P, q, A, l, u] (CuCaQP.cpp:271-288) or a models.LocalSystem; return values are dropped like the reference"""
         self.isInitialized_ = False
         self._result = None
-        self._vectors_only = False
+        self._vectors_dirty = self._matrices_dirty = False
         if hasattr(localSystem, "Pp"):
             ls = localSystem
             localSystem = [(ls.Pp, ls.Pi, ls.P), ls.q, (ls.Ap, ls.Ai, ls.A), ls.l, ls.u]
@@ -216,6 +233,7 @@ class CuCaQP:
                 except _lib.MpcqpError:
                     pass                                  # streaming kernel variant: every solve is a full setup
             self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
+            self._vectors_dirty = self._matrices_dirty = self._solved_once = False
             if self._start is not None:
                 self._qp.warm_start(self._start[0], self._start[1])
             self._qp.set_rho(self._rho0)
@@ -228,10 +246,13 @@ class CuCaQP:
         if not self.isInitialized_:
             return _err("Solver not initialized. Call initSolver() first.")
         try:
-            if getattr(self, "_vectors_only", False):
+            if self._vectors_dirty and self._kept and self._solved_once and not self._matrices_dirty:
                 self._qp.update_vectors(self.gradient, self.lowerBound, self.upperBound)
-                self._vectors_only = False
+            elif self._vectors_dirty or self._matrices_dirty:
+                self._qp.update(self._P[2], self.gradient, self._A[2], self.lowerBound, self.upperBound)
+            self._vectors_dirty = self._matrices_dirty = False
             self._qp.solve()
+            self._solved_once = True
             self._result = self._qp.get()
         except _lib.MpcqpError as e:
             return _err("Failed to solve problem. Error code: %d" % e.code)

@@ -67,17 +67,61 @@ def sum_over_ranks(value, dist):
 
 
 def gather_rows(local, dist, dst=0):
-    """Final gather of per-rank result rows (equal row count per rank) onto rank `dst`; returns the
-    concatenated array there and None elsewhere.  `local` is a NumPy array or a torch tensor."""
+    """Final gather of per-rank result rows onto rank `dst`; returns the concatenated array there and None
+    elsewhere.  Row counts may differ by rank (shard_range gives shards that differ by one row when the batch is
+    not a multiple of the world size): the counts are exchanged first and short shards are padded to the longest
+    for the collective, then trimmed.  `local` is a NumPy array or a torch tensor."""
     if dist is None:
         return local
     import torch
     t = local if hasattr(local, "data_ptr") else torch.from_numpy(np.ascontiguousarray(local))
     t = t.to(_dev(dist))
     world = dist.get_world_size()
+    counts = torch.zeros(world, dtype=torch.int64, device=t.device)
+    counts[dist.get_rank()] = t.shape[0]
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = [int(c) for c in counts.tolist()]
+    rows = max(counts)
+    if t.shape[0] < rows:
+        pad = torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=0)
+    t = t.contiguous()
     out = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
     dist.gather(t, out, dst=dst)
     if dist.get_rank() != dst:
         return None
-    cat = torch.cat(out, dim=0)
+    cat = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
     return cat if hasattr(local, "data_ptr") else cat.cpu().numpy()
+
+
+def launch_ranks(n_ranks, argv, extra_env=None):
+    """Start `n_ranks` fresh processes of the running script, one per GPU, with the torch.distributed rendezvous
+    variables set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / MASTER_PORT = a free port), wait for all of
+    them and return the worst exit code.  Called BEFORE anything touches the GPU (a process that has initialised HIP must
+    not be replaced or forked); the children are ordinary child processes, rank 0's stdout passes through.  A child that
+    fails ends the others."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:
+                    q.terminate()
+    return rc

@@ -6,7 +6,10 @@ each = evaluate the local system at the current iterate (getLocalSystem, :100-12
 initSolver / solve (:155-157, return values ignored) -> result.x += alpha * solution[pSize:] (:171-177) ->
 objective (:180-181).  Quirks kept on purpose: arg["x0"] is ignored and the iterate persists
 across calls (zero-initialised, :88-91); no line search or convergence test; the ||dx|| < 1e-6 early stop
-exists only when verbose (:183-197).
+exists only when verbose (:183-197).  Opt-in extension: options["sqp_tol"] = t > 0 adds
+a real convergence stop that does not depend on `verbose` -- the loop ends after the first iteration in which every
+instance of the batch moved by less than t (max-norm of the step actually taken, alpha * dx: what mpcqp_stage_step
+reports per instance); `iterations_done` tells how many iterations ran.  Without the option the loop is the reference's.
 
 The model supplies what CasADi's generated localSystemFunction_ supplies in the reference
 (optimal_control_problem_amd.models).  The QP backend is any object with the CuCaQP interface.
@@ -43,6 +46,9 @@ class SQPOptimizationSolver:
         self.warm_start_admm = bool(options.get("warm_start_admm", False))
         # and carry each instance's adapted rho into its next QP, as a kept OSQP workspace would (with warm_start_admm)
         self.carry_rho = bool(options.get("carry_rho", False))
+        self.sqp_tol = float(options.get("sqp_tol", 0.0) or 0.0)
+        self.iterations_done = 0
+        self.step_max = None
         self.admm_iterations = []
 
     def setVerbose(self, verbose):
@@ -90,11 +96,15 @@ class SQPOptimizationSolver:
             oldRes = self.result_["x"].copy()
             self.result_["x"] = self.result_["x"] + self.alpha_ * solution[:, pSize:]
             self.result_["f"] = self.model.objective(p, self.result_["x"])
+            self.iterations_done = i + 1
+            self.step_max = np.abs(self.alpha_ * solution[:, pSize:]).max(axis=1)
             if self.verbose_:
                 normDelta = np.linalg.norm(self.result_["x"] - oldRes, axis=1).max()
                 print("SQP iter %d/%d  max|dx| %.3e  f[0] %.6g" % (i + 1, self.stepNum_, normDelta, self.result_["f"][0]))
                 if normDelta < 1e-6:
                     break
+            if self.sqp_tol > 0.0 and np.nanmax(self.step_max) < self.sqp_tol:
+                break
         return {"x": self.result_["x"].copy(), "f": self.result_["f"].copy()}
 
 
@@ -120,6 +130,9 @@ class DeviceSQPOptimizationSolver:
         # q, l, u are replaced on the kept workspace (mpcqp_update_vectors): no equilibration, no factorisation.  The caller
         # asserts the matrices are constant, exactly as with OSQP's osqp_update_data_vec.
         self.constant_matrices = bool(options.get("constant_matrices", False))
+        self.sqp_tol = float(options.get("sqp_tol", 0.0) or 0.0)      # opt-in convergence stop, see the module docstring
+        self.iterations_done = 0
+        self.step_max = None
         self._kept = False
         self.batch = int(batch)
         self.ev = StageEvaluator(nlp, device=device, codegen=codegen)
@@ -186,11 +199,15 @@ class DeviceSQPOptimizationSolver:
             step = ev.step(self.alpha_, self.dw, self.x, stream=stream, status=self.status if self.skip_failed_steps else None)
             self.f, self.gmax = ev.merit(p, self.x, stream=stream)
             self.admm_iterations.append(self.iters.clone())
+            self.iterations_done = i + 1
+            self.step_max = step
             if self.verbose_:
                 normDelta = float(step.max())
                 print("SQP iter %d/%d  max|dx| %.3e  f[0] %.6g" % (i + 1, self.stepNum_, normDelta, float(self.f[0])))
                 if normDelta < 1e-6:
                     break
+            if self.sqp_tol > 0.0 and float(torch.nan_to_num(step, nan=0.0).max()) < self.sqp_tol:   # one scalar back to the host per iteration
+                break
         if not to_host:
             return {"x": self.x, "f": self.f}
         return {"x": self.x.cpu().numpy(), "f": self.f.cpu().numpy()}

@@ -442,6 +442,31 @@ def test_cucaqp_update_members_use_the_kept_workspace(built):
     qp.close()
 
 
+def test_cucaqp_updates_reach_the_device_in_every_order(built):
+    """the orders the bookkeeping has to survive: a vector update between initSolver() and the first solve(), a matrix update
+    (full setup at the next solve), vectors after it (kept workspace again) -- each against a fresh oracle solve of the data that
+    must be in effect"""
+    from optimal_control_problem_amd.cucaqp import CuCaQP
+    B = 4
+    mdl, ls, meta = models.make_workload("double_integrator", B)
+    mk = lambda P, q, A, l, u: models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, P, q, A, l, u)
+    qp = CuCaQP(batch=B); qp.setDimension(ls.n, ls.m); qp.setSystem(ls)
+    assert qp.initSolver()
+    q2 = ls.q * 0.7 + 0.05
+    assert qp.updateGradient(q2) and qp.solve()                  # initSolver() -> updateGradient() -> solve(): q2 must be what is solved
+    ref = problems.oracle_solve(mk(ls.P, q2, ls.A, ls.l, ls.u))
+    assert (qp.getIterations() == ref["iters"]).all() and np.abs(qp.getSolution() - ref["x"]).max() < 1e-6
+    P2 = ls.P * 1.5
+    assert qp.updateHessianMatrix((ls.Pp, ls.Pi, P2)) and qp.solve()
+    ref = problems.oracle_solve(mk(P2, q2, ls.A, ls.l, ls.u))
+    assert (qp.getIterations() == ref["iters"]).all() and np.abs(qp.getSolution() - ref["x"]).max() < 1e-6
+    A2 = ls.A.copy(); A2[..., np.asarray(ls.Ai) >= ls.n] *= 0.9   # dynamics rows only; the identity rows keep their ones
+    assert qp.updateLinearConstraintsMatrix((ls.Ap, ls.Ai, A2)) and qp.updateUpperBound(ls.u + 0.02) and qp.solve()
+    ref = problems.oracle_solve(mk(P2, q2, A2, ls.l, ls.u + 0.02))
+    assert (qp.getIterations() == ref["iters"]).all() and np.abs(qp.getSolution() - ref["x"]).max() < 1e-6
+    qp.close()
+
+
 def test_dispatch_hint_changes_no_result(built):
     """the longest-first dispatch order (taken from the previous solve's iteration counts) only permutes which workgroup takes
     which instance: bitwise identical outputs with a fresh handle (identity order), with its own history, and with the

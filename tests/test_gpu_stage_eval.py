@@ -103,6 +103,51 @@ def test_device_sqp_equals_host_sqp(built, name, N, alpha, warm):
     host.qpSolver_.close(); dev.close()
 
 
+def test_config4_cartpole_n100_warm_started_sqp(built):
+    """BASELINE.json configs[3] as stated: cart-pole swing-up, N = 100, fixed-step SQP (alpha = 0.5), ADMM of each QP warm-started
+    from the previous SQP iteration.  The device-resident loop against the host loop over the CPU oracle (same bar as
+    test_device_sqp_equals_host_sqp; 8 SQP iterations, 16 instances keep the oracle cheap)."""
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 16
+    mdl, ls, meta = models.make_workload("cartpole", B, N=100)
+    arg = dict(lbx=meta["lbx"], ubx=meta["ubx"], lbg=meta["lbg"], ubg=meta["ubg"], p=meta["p"])
+    opt = {"max_iter": 8, "alpha": 0.5, "warm_start_admm": True}
+    host = SQPOptimizationSolver(mdl, opt, batch=B, qp_solver=OracleCuCaQP(batch=B, nthreads=8))
+    dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B)
+    host.setInitialGuess(meta["x_iterate"]); dev.setInitialGuess(meta["x_iterate"])   # SURVEY 8d: hanging pole, theta ~ pi + N(0, 0.05^2)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    scale = 1.0 + np.abs(rh["x"]).max()
+    assert np.isfinite(rd["x"]).all()
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * scale
+    assert _close(rd["f"], rh["f"], 1e-6)
+    ih = np.stack(host.admm_iterations); idv = np.stack([t.cpu().numpy() for t in dev.admm_iterations])
+    assert ih.shape == (8, B) and (ih == idv).mean() >= 0.95
+    assert idv[-1].mean() < idv[0].mean()                      # the warm start pays: late QPs need fewer ADMM iterations than the first
+    dev.close()
+
+
+def test_sqp_tol_stops_both_loops_at_the_same_iteration(built):
+    """opt-in convergence stop: every instance's step below sqp_tol ends the loop -- without `verbose`,
+    unlike the reference's only stop (SQPOptimizationSolver.cpp:183-197).  Device loop = host loop, fewer iterations than step_num;
+    with the option absent both run the fixed count."""
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    B = 16
+    mdl, ls, meta = models.make_workload("double_integrator", B)
+    arg = dict(lbx=meta["lbx"], ubx=meta["ubx"], lbg=meta["lbg"], ubg=meta["ubg"], p=meta["p"])
+    opt = {"max_iter": 12, "alpha": 1.0, "sqp_tol": 1e-2}
+    host = SQPOptimizationSolver(mdl, opt, batch=B); dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    assert host.iterations_done == dev.iterations_done and 1 < dev.iterations_done < 12
+    assert float(dev.step_max.max()) < 1e-2 and host.step_max.max() < 1e-2
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * (1.0 + np.abs(rh["x"]).max())
+    host.qpSolver_.close(); dev.close()
+    plain = DeviceSQPOptimizationSolver(mdl, {"max_iter": 5, "alpha": 1.0}, batch=B)
+    plain.getOptimalSolution(arg)
+    assert plain.iterations_done == 5
+    plain.close()
+
+
 def test_stage_errors(built):
     from optimal_control_problem_amd import _lib
     from optimal_control_problem_amd.stage_eval import StageDesc, StageEvaluator, _bind

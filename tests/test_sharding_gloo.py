@@ -17,7 +17,7 @@ from optimal_control_problem_amd import models, sharding
 from tests.support import problems
 rank, world, local, dist = sharding.init_distributed(2, backend="gloo")
 assert world == 2
-mdl, ls, _ = models.make_workload("double_integrator", 10, seed=99)
+mdl, ls, _ = models.make_workload("double_integrator", 11, seed=99)      # 6 + 5 rows: uneven shards
 a, b = sharding.shard_range(ls.batch, rank, world)
 mine = models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[a:b], ls.q[a:b], ls.A[a:b], ls.l[a:b], ls.u[a:b])
 res = problems.oracle_solve(mine)
@@ -64,3 +64,22 @@ def test_two_rank_gloo(built, tmp_path):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK" in outs[0]
+
+
+def test_launch_ranks_starts_one_process_per_rank(built, tmp_path):
+    """bench.py's own launcher (plain `python bench.py --gpus N`): N child processes with the rendezvous variables set, rank 0's
+    stdout passed through, a failing rank reported in the exit code"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    drv = tmp_path / "driver.py"
+    drv.write_text("import sys\nsys.path.insert(0, %r)\nfrom optimal_control_problem_amd import sharding\n"
+                   "raise SystemExit(sharding.launch_ranks(2, [%r]))\n" % (ROOT, str(script)))
+    r = subprocess.run([sys.executable, str(drv)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(30)\n")
+    drv.write_text("import sys\nsys.path.insert(0, %r)\nfrom optimal_control_problem_amd import sharding\n"
+                   "raise SystemExit(sharding.launch_ranks(2, [%r]))\n" % (ROOT, str(bad)))
+    r = subprocess.run([sys.executable, str(drv)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode == 7
