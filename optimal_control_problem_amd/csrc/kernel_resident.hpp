@@ -22,7 +22,6 @@ struct DevRes {
   int tmp_alias;   // global-block plans: the factorisation's temp tiles alias w (plan.hpp gb_tmp_alias)
 };
 
-template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
 
 struct RCtx {
   const DevPlan *pl; const DevRes *rs; const mpcqp_settings *st; double *ws;
@@ -554,10 +553,15 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 // CU anyway (the kernel may then use the whole register file), 2 otherwise
 // GB = the factor blocks stay in the per-QP HBM slab (factors that do not fit LDS); LDS then holds only the temp
 // tiles, the ADMM vectors and the schedule, and the segment loops keep several blocks in flight.
-template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false>
-__global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io) {
+// OCG > 0 (with GB): the on-chip solve of kernel_onchip.hpp -- the factorisation still works in the slab (its tiles and the temp
+// tiles are dead outside it), then the factor is brought on chip: LDS block slots + OCG inverse diagonal blocks and OCH hub blocks
+// per wave in registers.
+template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false, int OCG = 0, int OCH = 0>
+__global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
+  constexpr bool OC = OCG > 0;
+  static_assert(!OC || (GB && !ZYG && NW == 4), "the on-chip solve is a mode of the 4-wave global-block kernel");
   constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
   constexpr int EU = 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -578,6 +582,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 16 * NW);     // (block_combine needs 15 * NW) [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
+  int *octab = reinterpret_cast<int *>(cx.RED + 16 * NW) + 8;   // on-chip solve: its table (8-byte aligned pairs) instead of schedule segments
+  double *ocBL = lds;                                           // ... and the LDS block slots (the temp tiles of the factorisation alias them)
+  d4 ocG[OC ? OCG : 1], ocHF[OCH > 0 ? OCH : 1], ocHT[OCH > 0 ? OCH : 1];
+  OcLane ocl; OcWave<OC ? OCG : 1> ocw;
   double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
   double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
   const double *inP = io.P + (long)b * io.sP, *inA = io.A + (long)b * io.sA, *inq = io.q + (long)b * io.sq;
@@ -586,8 +594,13 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   cx.unscale = st.scaling && !st.scaled_termination;
 
   TS_DECL;
-  for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
-  if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
+  if constexpr (OC) {
+    for (int k = tid; k < oc.o_pos; k += NT) octab[k] = oc.tab[k];      // the chain tables; the rest is only read when the factor is loaded
+    ocl = oc_lane(lane);
+  } else {
+    for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
+    if (tid <= NW) lptr[tid] = rs.g_ptr[tid];
+  }
   double c = 1.0;
   int refactor = 1, prev_status = MPCQP_UNSOLVED;
   constexpr bool REUSE_T = REUSE;
@@ -703,6 +716,12 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     bsync<NW>();
   }
   if (!ok) status = MPCQP_NON_CVX;
+  if constexpr (OC) {
+    if (ok) {
+      ocw = oc_wave<NW, OCG, OCH>(oc, oc.tab, wid);
+      oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
+    }
+  }
   TS(3);
 
   int interval = st.adaptive_rho_interval;
@@ -710,7 +729,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   const double alpha = st.alpha, sigma = st.sigma;
   double *dxg = ws + pl.o_dx, *dyg = ws + pl.o_dy;
   int can_check = 0;
-  const int sq0 = lptr[wid], sq1 = lptr[wid + 1];
+  const int sq0 = OC ? 0 : lptr[wid], sq1 = OC ? 0 : lptr[wid + 1];
   const int ni_off = rs.nconst ? pl.nblk * BLK * 8 : -1;      // byte offset of the constant -I block (split accumulation runs)
   if (ok) {
     int iter;
@@ -719,14 +738,18 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
+      if constexpr (OC) {
+        oc_solve<NW, OCG, OCH>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
+      } else {
 #ifdef MPCQP_TIMING
-      long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
-      if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
-      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off, trace);
-      if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
+        long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
+        if (trace) trace[0] = (long long)__builtin_amdgcn_s_memtime();
+        run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off, trace);
+        if (trace) trace[1] = (long long)__builtin_amdgcn_s_memtime();
 #else
-      run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off);
+        run_schedule<NW, GB, SPD>(segs, sq0, sq1, reinterpret_cast<const char *>(cx.BL), reinterpret_cast<char *>(cx.R), lane, ni_off);
 #endif
+      }
       if (NW == 1) bsync<NW>();
       TS(5);
       can_check = st.check_termination && (iter % st.check_termination == 0);
@@ -778,6 +801,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
           cx.rho = uni(rn);
           if (!factorize_res<NW>(cx)) { status = MPCQP_NON_CVX; break; }
+          if constexpr (OC) oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
         }
       }
     }

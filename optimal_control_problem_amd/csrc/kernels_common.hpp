@@ -61,6 +61,8 @@ __device__ __forceinline__ double rho_of(double l, double u, double rho) {
 }
 // single-wave workgroup: orders LDS / global accesses between lanes of the wave
 __device__ __forceinline__ void wsync() { __syncthreads(); }
+// workgroup barrier of the multi-wave kernels
+template <int NW> __device__ __forceinline__ void bsync() { __syncthreads(); }
 
 // out(row, sum_s val * in[idx]) over an ELL structure; rows are lane-mapped, loads are 512 B coalesced
 template <class F>

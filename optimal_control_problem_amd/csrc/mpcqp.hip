@@ -13,6 +13,9 @@
 //     schedule, so that 3-4 workgroups share a CU (the default for the 12-state quadrotor sizes; HBM-roofline-bound).
 //     MINW selects the register budget (128 / 168 / 256 VGPRs), REUSE the kept-workspace entry (mpcqp_update_vectors),
 //     ZYG keeps z and y in the slab too (long horizons).
+//     OCG / OCH > 0: the on-chip mode of the global-block kernel (kernel_onchip.hpp) -- after each factorisation the factor is
+//     brought on chip (chain blocks in LDS, inverse diagonal blocks and some hub blocks in registers; two workgroups per CU) and the
+//     triangular solves run on the matrix cores, register to register along each chain.  The default for the 12-state quadrotor, N = 20.
 //   * mpcqp_admm_kernel<PD> -- the first-generation streaming kernel, one QP per wavefront, block Cholesky streamed from
 //     the slab; fallback when even the vectors exceed LDS, and a cross-check in the variant tests.
 // Common to all: ADMM iterates in LDS; scaled A in two ELL orientations and scaled P in the slab, streamed with coalesced
@@ -39,6 +42,7 @@
 using namespace mpcqp;
 #include "kernels_common.hpp"
 #include "kernel_stream.hpp"
+#include "kernel_onchip.hpp"
 #include "kernel_resident.hpp"
 #include "kernels_util.hpp"
 
@@ -75,6 +79,8 @@ struct mpcqp_handle {
   int res3 = 0;                 // LDS-resident 4-wave kernel: 3 or 4 workgroups per CU (168- / 128-VGPR instances) when the LDS footprint allows, else 0
   bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
+  bool oc = false;              // on-chip mode of the global-block kernel (kernel_onchip.hpp): two workgroups per CU, factor in LDS + registers
+  OcPlan ocplan; DevOc doc;
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
@@ -122,10 +128,15 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
   return MPCQP_OK;
 }
 
+// register-resident blocks per wave of the on-chip instance: inverse diagonal blocks (positions per wave) and hub blocks
+constexpr int OC_NG = 5, OC_NH = 3;
+constexpr long OC_LDS_MAX = 80 * 1024;      // two workgroups per CU
+
 // the kernel instance a handle runs: waves per QP, register budget, factor location, and -- as its own instance so that the
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->oc) return (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH>;
   if (h->gblocks && h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, true, REUSE>;
   if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
   if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
@@ -201,6 +212,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       else if (v == "gres4") { want = 4; h->gblocks = true; }
       else if (v == "res2") want = 2;
       else if (v == "gres2") { want = 2; h->gblocks = true; }
+      else if (v == "oc4") { want = 4; h->gblocks = true; h->oc = true; }
     }
     // candidate plans of the multi-wave kernels: ELL chunk widths padded to multiples of 4 (fewer load batches per chunk)
     // and the stage chain eliminated from both ends (two concurrent half-length chains)
@@ -246,26 +258,40 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         // four workgroups there (double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB
         // and above four waves win)
         else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) { want = 2; h->gblocks = true; }
-        else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; }
+        else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; h->oc = !getenv("MPCQP_NO_OC"); }
         else want = 0;
       }
     }
+    if (h->oc) {
+      // on-chip mode: block tridiagonal (+ arrow) patterns whose factor fits LDS + registers at two workgroups per CU; the largest number
+      // of LDS block slots that keeps the footprint within 80 KB is searched from above
+      const ResPlan r4 = build_res_plan(p4, 4, false);
+      h->oc = false;
+      const OcPlan all = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();     // every block in LDS: is it this topology at all?
+      for (int nl = all.ok ? all.nlds : 0; nl >= 1; nl--) {
+        const OcPlan o = build_oc_plan(p4, 4, nl, OC_NG, OC_NH);
+        if (!o.ok) break;                                      // would need more register-resident hub blocks than the instance has
+        if (lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) { h->ocplan = o; h->oc = true; break; }
+      }
+      if (!h->oc && want == 4 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc4")
+        return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));
+    }
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
-      h->rplan = build_res_plan(pl, want, h->gblocks);
-      long need = h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
-      if (h->gblocks && !getenv("MPCQP_NO_ZYG")) {
+      h->rplan = build_res_plan(pl, want, h->gblocks && !h->oc);
+      long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      if (h->gblocks && !h->oc && !getenv("MPCQP_NO_ZYG")) {
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
         const long alt = lds_bytes_res_gb(pl, h->rplan, true);
         const long fit = LDS_MAX / need, fit_alt = std::min<long>(LDS_MAX / alt, 3);
         if (fit <= 2 && fit_alt > fit) { h->zyg = true; need = alt; }
       }
-      h->occ4 = h->gblocks && !h->zyg && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
+      h->occ4 = h->gblocks && !h->oc && !h->zyg && need <= 53 * 1024 && !getenv("MPCQP_GB_OCC2");
       // LDS between 40 and 53 KiB: three workgroups per CU fit, so the instance compiled for three waves per SIMD (168 VGPRs, no
       // spills, 8 blocks in flight) replaces the 128-VGPR one (at 42 KiB 92.9k -> 95.8k QP/s on cart-pole N=100, which now fits four per CU
       // because the temp tiles alias w, plan.hpp gb_tmp_alias: 76.2 -> 73.2 ms per 8192; at 32 KiB it loses, 589k -> 551k)
       // (with z and y in the slab the 168-VGPR instance at three per CU also beats the 128-VGPR one at four: quadrotor N=50 23.9 vs 26.0 ms)
-      h->occ3 = h->gblocks && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
+      h->occ3 = h->gblocks && !h->oc && need <= 53 * 1024 && (need > 40 * 1024 || h->zyg || getenv("MPCQP_GB_OCC3")) && !getenv("MPCQP_GB_OCC2");
       if (!small_ok || need > LDS_MAX) return bail(fail(MPCQP_ERR_LIMIT, "resident variant needs " + std::to_string(need) + " B of LDS"));
       h->lds = need;
       h->res1x = want == 1 && !h->gblocks && LDS_MAX / need > 8 && !getenv("MPCQP_NO_RES1X");
@@ -298,7 +324,15 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     UP(upload(h, rp.lw_slot, &dr.lw_slot)); UP(upload(h, rp.lw_g, &dr.lw_g)); UP(upload(h, rp.lu_ptr, &dr.lu_ptr));
     UP(upload(h, rp.lu_dst, &dr.lu_dst)); UP(upload(h, rp.lu_tmp, &dr.lu_tmp)); UP(upload(h, rp.lu_b, &dr.lu_b));
     UP(upload(h, rp.g_ptr, &dr.g_ptr)); UP(upload(h, rp.g_seg, &dr.g_seg)); dr.n_seg = (int)rp.g_seg.size() / 8; dr.stage = h->gblocks ? res_stage_doubles_gb(pl, rp) : res_stage_doubles(pl, rp);
-    dr.tmp_alias = h->gblocks && gb_tmp_alias(pl, rp) ? 1 : 0;
+    dr.tmp_alias = h->gblocks && !h->oc && gb_tmp_alias(pl, rp) ? 1 : 0;
+    memset(&h->doc, 0, sizeof(h->doc));
+    if (h->oc) {
+      const OcPlan &o = h->ocplan; DevOc &d = h->doc;
+      dr.stage = oc_stage_doubles(o, rp); dr.rext = OC_REXT; dr.nconst = 0; dr.n_seg = 0;
+      d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
+      d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot;
+      UP(upload(h, o.tab, &d.tab));
+    }
   }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
@@ -452,7 +486,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
   HIPCHK(hipEventRecord(h->ev0, s));
   if (h->variant > 0) {
-    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
+    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, io.reuse != 0), dim3(h->batch), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
   else if (h->stream_pd8) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(h->batch), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
@@ -487,7 +521,7 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
   if (io.dbg) io.dbg += 16L * b0;
   io.order = nullptr;
   if (h->variant > 0) {
-    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io};
+    void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, false), dim3(count), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
   else if (h->stream_pd8) hipLaunchKernelGGL(mpcqp_admm_kernel<8>, dim3(count), dim3(WAVE), (size_t)h->lds, s, h->dp, h->st, io);
@@ -610,7 +644,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
   o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
-  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->gblocks ? 100 + h->variant : h->variant;
+  o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->oc ? 200 + h->variant : h->gblocks ? 100 + h->variant : h->variant;
   return MPCQP_OK;
 }
 

@@ -660,6 +660,116 @@ inline long lds_bytes_res(const Plan &pl, const ResPlan &rp) {
   return (res_stage_doubles(pl, rp) + 3L * pl.npad + rp.rext + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + sched_words) * 8L;
 }
 
+// ---- "on-chip" variant (kernel_onchip.hpp): the whole factor stays on the CU at two workgroups per CU -- chain blocks and part
+// of the hub blocks in LDS (one copy serves the forward sweep and, read transposed, the backward sweep), the inverse diagonal
+// blocks G_p and the remaining hub blocks in registers -- and the solve is written for the one topology MPC problems have: block
+// tridiagonal (one or two elimination chains: plain or twisted order) plus an optional arrow (the hub block, last).
+//   position p < nbc: a block of the chain part; hub position = nbc (when has_hub).  succ(p) = the one non-hub off-diagonal block
+//   row of column p.  Two chains may meet in their common last element f (twisted order): chainE ends with e, succ(e) = f = the
+//   last element of chainF.
+// Every mat-vec runs on the matrix cores (v_mfma_f64_16x16x4_f64, vector in the B operand's column 0): the result layout of one
+// op is the operand layout of the next, so a chain runs register to register.
+struct OcPlan {
+  bool ok = false;
+  int nbc = 0, has_hub = 0, junc = 0;
+  std::vector<int> chainE, chainF;          // positions in elimination (forward) order
+  int npw = 0;                              // positions per wave in the wave-parallel phases: wave w owns p = w + 4 s, s < npw
+  int nhr = 0;                              // hub blocks of the positions with s < nhr live in registers (both layouts), the rest in LDS
+  int nlds = 0;                             // LDS block slots
+  std::vector<int> gsrc, csrc, hsrc;        // [nbc] factor block ids (slab order): G_p, W_succ(p),p or -1, W_hub,p or -1
+  std::vector<int> cslot, hslot;            // [nbc] LDS slot of the chain / hub block of column p, -1 = none (hub: -1 also when in registers)
+  int ghub_src = -1, ghub_slot = -1;
+  // flattened for the device: [0] LE [1] LF, then chainE and chainF as {position, LDS slot of W_succ(p),p} pairs (8-byte aligned),
+  // then per position {gsrc, csrc, hsrc, cslot, hslot}, then the LDS fill list {src, slot, negate} x nlds
+  std::vector<int> tab;
+  int o_chainE = 0, o_chainF = 0, o_pos = 0, o_fill = 0;
+};
+constexpr int OC_REXT = 5 * BS;             // behind the solve vector: the junction term and one hub partial sum per wave
+
+inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_npw, int max_nhr) {
+  OcPlan oc;
+  const int nb = pl.nb;
+  if (nb < 2 || nw != 4) return oc;
+  std::map<std::pair<int, int>, int> bid;
+  for (int b = 0; b < pl.nblk; b++) bid[{pl.blkI[b], pl.blkJ[b]}] = b;
+  const int H = nb - 1;
+  // is the last block an arrow head?  It is when some column has it beside a chain successor; a last block that only its neighbour
+  // couples to is the end of the chain
+  int hub_cols = 0, hub_with_chain = 0;
+  for (int p = 0; p < H; p++) {
+    const std::vector<int> &rows = pl.colrows[p];
+    const bool hh = std::find(rows.begin(), rows.end(), H) != rows.end();
+    if ((int)rows.size() - (hh ? 1 : 0) > 1) return oc;                 // more than one chain successor: not this topology
+    if (hh) { hub_cols++; if (rows.size() > 1) hub_with_chain++; }
+  }
+  oc.has_hub = hub_with_chain > 0 || hub_cols > 1;
+  oc.nbc = oc.has_hub ? nb - 1 : nb;
+  const int nbc = oc.nbc;
+  std::vector<int> succ(nbc, -1), npred(nbc, 0);
+  for (int p = 0; p < nbc; p++)
+    for (int I : pl.colrows[p]) { if (oc.has_hub && I == H) continue; succ[p] = I; npred[I]++; }
+  std::vector<int> heads;
+  for (int p = 0; p < nbc; p++) { if (npred[p] == 0) heads.push_back(p); if (npred[p] > 2) return oc; }
+  if (heads.empty() || heads.size() > 2) return oc;
+  auto walk = [&](int h) { std::vector<int> c; for (int p = h; p >= 0; p = succ[p]) c.push_back(p); return c; };
+  std::vector<int> c0 = walk(heads[0]), c1 = heads.size() == 2 ? walk(heads[1]) : std::vector<int>();
+  if (heads.size() == 2) {
+    // the two chains must share exactly their last element
+    if (c0.back() != c1.back()) return oc;
+    for (size_t i = 0; i + 1 < c0.size(); i++) if (std::find(c1.begin(), c1.end(), c0[i]) != c1.end()) return oc;
+    // E = the chain that hands its end over (drops the shared element), F keeps it; give F the longer one so both waves do the same work
+    if (c0.size() > c1.size()) std::swap(c0, c1);
+    c0.pop_back();
+    oc.chainE = c0; oc.chainF = c1; oc.junc = 1;
+    if (oc.chainE.empty()) { oc.junc = 0; oc.chainE = c1; oc.chainF.clear(); }
+  } else {
+    oc.chainE = c0;
+  }
+  if ((int)(oc.chainE.size() + oc.chainF.size()) != nbc) return oc;
+  oc.npw = (nbc + nw - 1) / nw;
+  if (oc.npw > max_npw) return oc;
+  oc.gsrc.assign(nbc, -1); oc.csrc.assign(nbc, -1); oc.hsrc.assign(nbc, -1); oc.cslot.assign(nbc, -1); oc.hslot.assign(nbc, -1);
+  int slots = 0;
+  for (int p = 0; p < nbc; p++) {
+    oc.gsrc[p] = bid.at({p, p});
+    if (succ[p] >= 0) { oc.csrc[p] = bid.at({succ[p], p}); oc.cslot[p] = slots++; }
+    if (oc.has_hub) { auto it = bid.find({H, p}); if (it != bid.end()) oc.hsrc[p] = it->second; }
+  }
+  if (oc.has_hub) { oc.ghub_src = bid.at({H, H}); oc.ghub_slot = slots++; }
+  // hub blocks: LDS while it lasts, filled from the last positions down; the first nhr slots of every wave go to registers
+  oc.nhr = 0;
+  if (oc.has_hub) {
+    while (true) {
+      int need = 0;
+      for (int p = 0; p < nbc; p++) if (oc.hsrc[p] >= 0 && p / nw >= oc.nhr) need++;
+      if (slots + need <= max_lds_blocks) break;
+      if (++oc.nhr > max_nhr) return oc;
+    }
+    for (int p = 0; p < nbc; p++) if (oc.hsrc[p] >= 0 && p / nw >= oc.nhr) oc.hslot[p] = slots++;
+  }
+  if (slots > max_lds_blocks) return oc;
+  oc.nlds = slots;
+  // device table
+  oc.tab.push_back((int)oc.chainE.size()); oc.tab.push_back((int)oc.chainF.size());
+  oc.o_chainE = (int)oc.tab.size(); for (int p : oc.chainE) { oc.tab.push_back(p); oc.tab.push_back(oc.cslot[p]); }
+  oc.o_chainF = (int)oc.tab.size(); for (int p : oc.chainF) { oc.tab.push_back(p); oc.tab.push_back(oc.cslot[p]); }
+  oc.o_pos = (int)oc.tab.size();
+  for (int p = 0; p < nbc; p++) { int r[5] = {oc.gsrc[p], oc.csrc[p], oc.hsrc[p], oc.cslot[p], oc.hslot[p]}; oc.tab.insert(oc.tab.end(), r, r + 5); }
+  oc.o_fill = (int)oc.tab.size();
+  for (int p = 0; p < nbc; p++) if (oc.cslot[p] >= 0) { int r[3] = {oc.csrc[p], oc.cslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  if (oc.has_hub) { int r[3] = {oc.ghub_src, oc.ghub_slot, 0}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  for (int p = 0; p < nbc; p++) if (oc.hslot[p] >= 0) { int r[3] = {oc.hsrc[p], oc.hslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  oc.ok = true;
+  return oc;
+}
+// LDS of the on-chip variant: block slots (the factorisation's temp tiles and the staged ELL values alias them), x, q, r (+ the
+// junction / hub partial sums) [npad], z, y, w [mpad], reduction scratch, the table
+inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp) { return (long)std::max(oc.nlds, rp.ntemp) * BLK; }
+inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc) {
+  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4;      // the chain tables live in LDS; the per-position and fill tables are read from global memory
+  return (oc_stage_doubles(oc, rp) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
+}
+
 inline long lds_bytes(const Plan &pl) {
   // x, q, r [npad]; z, y, w [mpad]; two padded 16x17 scratch tiles (aliased onto r when npad >= 544); 64 spare doubles
   const long tiles = pl.npad >= 2 * BS * (BS + 1) ? 0 : 2L * BS * (BS + 1);

@@ -322,6 +322,32 @@ def test_kernel_variants_vs_oracle(built, monkeypatch, variant, name, batch, N):
         _close(got, ref, k)
 
 
+@pytest.mark.parametrize("name,batch,N", [("quadrotor", 24, 20), ("quadrotor", 7, 12), ("cartpole", 6, 30), ("double_integrator", 40, 20),
+                                          ("double_integrator", 9, 60), ("cartpole", 5, 50)])
+def test_onchip_variant_vs_oracle(built, monkeypatch, name, batch, N):
+    """the on-chip mode (factor in LDS + registers, triangular solves on the matrix cores; kernel_onchip.hpp): twisted two-chain
+    plans with a hub (quadrotor), single chains whose hub shares the last block (cart-pole), tiny plans, runs long enough for an
+    adaptive-rho refactorisation (double integrator) -- same bar as every other family"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "oc4")
+    mdl, ls, _ = models.make_workload(name, batch, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info()
+    assert info["variant"] == 204 and info["lds_bytes"] <= 80 * 1024
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+
+
+def test_onchip_is_the_default_for_the_north_star_size(built):
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("quadrotor", 2, N=20)
+    qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+    assert info["variant"] == 204 and info["lds_bytes"] <= 80 * 1024
+
+
 @pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "gres4", "gres2"])
 def test_kernel_variants_hard_cases(built, monkeypatch, variant):
     """adaptive-rho refactorisation, infeasibility certificates, max-iter exit, non-convex rejection per kernel family"""
@@ -351,7 +377,7 @@ def test_kernel_variants_hard_cases(built, monkeypatch, variant):
 # ---------------------------------------------------------------------------------------------- kept workspace
 @pytest.mark.parametrize("variant,name,B,N", [(None, "double_integrator", 24, 20), ("res1", "double_integrator", 24, 20),
                                               ("gres4", "double_integrator", 24, 20), ("res4", "cartpole", 12, 30),
-                                              ("gres4", "quadrotor", 10, 10)])
+                                              ("gres4", "quadrotor", 10, 10), ("oc4", "quadrotor", 10, 20), ("oc4", "double_integrator", 24, 20)])
 def test_kept_workspace_vectors_vs_oracle(built, monkeypatch, variant, name, B, N):
     """mpcqp_keep_workspace + mpcqp_update_vectors (OSQP's osqp_update_data_vec on a kept workspace: scaling, factor and the
     adapted rho stay) against the oracle's kept workspaces, on every kernel family: a full solve, a q/l/u-only solve, a
