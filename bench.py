@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed region only: skip the in-order, PCIe-inclusive and CPU-baseline legs (profiling runs)")
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
-    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4"])
+    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4", "oc4"])
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 flow on a one-GPU box: all ranks use cuda:0, collectives over gloo")
     ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
     args = ap.parse_args()
@@ -180,19 +180,21 @@ def main():
                          # the same launch priced on its measured HBM traffic instead of the algorithmic bytes
                          "achieved_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9,
                          "frac_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel": "mpcqp_res_kernel" if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
+                         "kernel": ("mpcqp_res_kernel (on-chip mode)" if pinfo["variant"] >= 200 else "mpcqp_res_kernel") if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max,
                          "algorithmic_bytes_per_solve": abytes,
                          # flops of one ADMM iteration = two block-triangular solves + A x, A'y + P x + vector work
                          "algorithmic_flops_per_admm_iter": flops_iter,
                          "achieved_tflops_fp64": flops_iter * (iters_sum / world) / (kms * 1e-3) / 1e12,
                          "fp64_vector_peak_tflops": FP64_VEC_PEAK_TFLOPS,
-                         "regime": ("factor blocks and A / A' values re-streamed from HBM every ADMM iteration (occupancy beats LDS residency at this size)"
+                         "regime": ("factor on chip (LDS + registers, two workgroups per CU); A / A' values re-read from L2 / Infinity Cache / HBM every ADMM iteration" if pinfo["variant"] >= 200 else
+                                    "factor blocks and A / A' values re-streamed from HBM every ADMM iteration (occupancy beats LDS residency at this size)"
                                     if pinfo["variant"] >= 100 or pinfo["variant"] == 0 else "factor resident in LDS; A / A' values re-read from L2 / HBM every ADMM iteration")},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
                             "admm_iters_per_s": iters_sum / (kms_max * 1e-3),
                             "lds_bytes_per_qp": pinfo["lds_bytes"], "workspace_bytes_per_qp": pinfo["workspace_bytes_per_qp"],
                             "L_blocks": pinfo["L_blocks"], "workload_gen_s": t_gen,
                             "kernel_variant": ("stream (1 wave/QP, Cholesky factor streamed from HBM)" if pinfo["variant"] == 0 else
+                                               "on-chip LDL' (%d waves/QP, factor in LDS + registers, solves on the matrix cores)" % (pinfo["variant"] - 200) if pinfo["variant"] >= 200 else
                                                "LDL' %d waves/QP, factor blocks streamed from HBM" % (pinfo["variant"] - 100) if pinfo["variant"] >= 100 else
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }

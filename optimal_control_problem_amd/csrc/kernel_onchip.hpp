@@ -63,9 +63,9 @@ __device__ __forceinline__ d4 oc_ldF(const double *blk, const OcLane &ln) {
 }
 __device__ __forceinline__ d4 oc_ldT(const double *blk, const OcLane &ln) { return d4{blk[ln.t0], blk[ln.t1], blk[ln.t2], blk[ln.t3]}; }
 __device__ __forceinline__ d4 oc_ldB(const double *vec, int p, const OcLane &ln) { return *reinterpret_cast<const d4 *>(vec + BS * p + ln.vb); }
-__device__ __forceinline__ void oc_stB(double *vec, int p, const OcLane &ln, const d4 v) {
-  if (ln.col0) *reinterpret_cast<d4 *>(vec + BS * p + ln.vb) = v;
-}
+// every column of an MFMA result holds the same vector: the 16 lanes of a group store identical data to one address (no exec-masked
+// branch, whose block boundary would cost the chain loops a full LDS wait)
+__device__ __forceinline__ void oc_stB(double *vec, int p, const OcLane &ln, const d4 v) { *reinterpret_cast<d4 *>(vec + BS * p + ln.vb) = v; }
 // acc += Block * v on the matrix cores (a: the block's A-operand registers of this lane, v: the vector in the B layout)
 __device__ __forceinline__ d4 oc_mv(const d4 a, const d4 v, d4 acc) {
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], v[0], acc, 0, 0, 0);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
       const int gs = oc_tab(tab, oc.o_pos + 5 * p), hs = oc_tab(tab, oc.o_pos + 5 * p + 2);
       G[s] = *reinterpret_cast<const d4 *>(slab + (long)gs * BLK + ln.gF);
       if (s < NH) {
-        if (s < oc.nhr && hs >= 0) {
+        if (hs >= 0) {
           const double *hb = slab + (long)hs * BLK;
           HF[s] = -*reinterpret_cast<const d4 *>(hb + ln.gF);
           HT[s] = -d4{hb[ln.gT], hb[ln.gT + BS], hb[ln.gT + 2 * BS], hb[ln.gT + 3 * BS]};
@@ -110,125 +110,159 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
   bsync<NW>();
 }
 
-// what a wave needs to know about its own positions p = wid + NW s, read once into scalar registers
+// what a wave needs to know about its own positions p = wid + NW s, read once into scalar registers.  Every loop over s is
+// straight-line code: a slot without a position ("phantom": nbc is not a multiple of NW) reads the zero block behind the solve
+// vector, multiplies a zero G and has its store switched off.
 template <int NG>
-struct OcWave { int hub[NG]; };     // >= 0: LDS slot of W_hub,p; -1: in this wave's registers; -2: no hub block (or no position)
+struct OcWave {
+  int vpos[NG];      // vector block to read: p, or the zero block for a phantom slot
+  int hslot[NG];     // LDS slot of W_hub,p for the slots s >= NH (any valid slot for a phantom)
+  int ok[NG];        // the slot has a position
+};
+constexpr int OC_MAXT = 8;       // chain loops are unrolled for up to 2 * OC_MAXT stages + 1: chains of at most 17 positions (plan.hpp checks)
+constexpr int OC_ZERO = 5;       // vector blocks behind the solve vector: 0 junction term, 1..4 hub partial sums, 5 zeros
 template <int NW, int NG, int NH>
-__device__ __forceinline__ OcWave<NG> oc_wave(const DevOc &oc, const int *tab, const int wid) {
+__device__ __forceinline__ OcWave<NG> oc_wave(const DevOc &oc, const int *tab, const int wid, const int npad) {
   OcWave<NG> ow;
 #pragma unroll
   for (int s = 0; s < NG; s++) {
-    const int p = wid + NW * s;
-    int h = -2;
-    if (p < oc.nbc && oc.has_hub && oc_tab(tab, oc.o_pos + 5 * p + 2) >= 0) h = (s < NH && s < oc.nhr) ? -1 : oc_tab(tab, oc.o_pos + 5 * p + 4);
-    ow.hub[s] = h;
+    const int p = wid + NW * s, pe = p < oc.nbc ? p : oc.nbc - 1;
+    ow.ok[s] = p < oc.nbc;
+    ow.vpos[s] = p < oc.nbc ? p : npad / BS + OC_ZERO;
+    const int hs = oc_tab(tab, oc.o_pos + 5 * pe + 4);
+    ow.hslot[s] = hs >= 0 ? hs : 0;
   }
   return ow;
 }
-__device__ __forceinline__ int2 oc_pair(const int *tab, int k) {
-  const int2 e = *reinterpret_cast<const int2 *>(tab + k);
-  return make_int2(__builtin_amdgcn_readfirstlane(e.x), __builtin_amdgcn_readfirstlane(e.y));
-}
+// a chain table entry {position, LDS slot}.  It stays in vector registers: it only feeds LDS addresses, which are per-lane anyway, and
+// a readfirstlane would make the wave wait for the entry -- and every LDS read issued before it -- in the middle of a stage
+__device__ __forceinline__ int2 oc_pair(const int *tab, int k) { return *reinterpret_cast<const int2 *>(tab + k); }
 
-// x = M^-1 rhs in place on the solve vector R (positions = blocks of 16; behind it the junction term and the waves' hub partials).
+// x = M^-1 rhs in place on the solve vector R (positions = blocks of 16; behind it the junction term, the waves' hub partials and a
+// zero block).
 //   F1  the chains, one wave each: t_succ(p) = rhs_succ(p) - W t_p, register to register; the wave of chain E ends with the
 //       junction term -W_f,e t_e (f = the shared last element, kept by chain F)
-//   F2  every wave, for its own positions p = wid + 4 s: hub partial sum  -sum W_hub,p t_p
+//   F2  the owner of f adds the junction term; every wave, for its own positions p = wid + 4 s: hub partial sum  -sum W_hub,p t_p
 //   F3  every wave: t_hub, x_hub = G_hub t_hub
 //   B1  every wave, own positions: d_p = G_p t_p - W_hub,p' x_hub
 //   B2  the chains backwards: x_p = d_p - W_succ(p),p' x_succ(p)
 // Chain tables are {position, LDS slot of the block below it} pairs; the entries, blocks and right-hand sides of the next stage
-// are fetched while the current stage multiplies.
-template <int NW, int NG, int NH>
+// are fetched while the current stage multiplies.  HUB: the pattern has an arrow head (has_hub); its first NH blocks per wave are
+// in registers (the host lays the plan out for exactly this instance).
+template <int NW, int NG, int NH, bool HUB>
 __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln, const OcWave<NG> &ow,
-                                         const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid) {
-  double *JUNC = R + npad, *HP = R + npad + BS;
+                                         const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
+                                         unsigned long long *stamp = nullptr) {
+#ifdef MPCQP_TIMING
+#define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
+  unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#else
+#define OC_TS(k)
+#endif
+  double *EXT = R + npad;                          // vector blocks behind the solve vector
   const int LE = oc_tab(tab, 0), LF = oc_tab(tab, 1);
   const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_chainE : oc.o_chainF;
   const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_chainF + 2 * (LF - 1)) : -1;
   const int H = oc.nbc;
   // ---- F1
+  // Two stages per trip with the roles of the two vector register sets swapped (x -> y -> x): no copy sits between an MFMA result
+  // and the MFMAs that read it as their B operand.  The next stage's block and right-hand side are loaded while a stage multiplies;
+  // table entries are read two stages ahead.
   if (wid < 2 && len > 0) {
-    int2 e = oc_pair(tab, cb);                      // stage k multiplies block e.y into position en.x
-    d4 v = oc_ldB(R, e.x, ln);
-    if (len > 1) {
-      int2 en = oc_pair(tab, cb + 2);
-      d4 a = oc_ldF(BL + (long)e.y * BLK, ln), c = oc_ldB(R, en.x, ln);
-      int2 enn = len > 2 ? oc_pair(tab, cb + 4) : en;
-      for (int k = 1; k < len; k++) {
-        d4 an = a, cn = c; int2 e3 = enn;
-        if (k + 1 < len) {
-          an = oc_ldF(BL + (long)en.y * BLK, ln); cn = oc_ldB(R, enn.x, ln);
-          if (k + 2 < len) e3 = oc_pair(tab, cb + 2 * (k + 2));
-        }
-        c = oc_mv(a, v, c);
-        oc_stB(R, en.x, ln, c);
-        v = c; e = en; en = enn; enn = e3; a = an; c = cn;
-      }
+    const int nst = len - 1;                           // stages: stage k multiplies block e[k].y into position e[k + 1].x
+    // (table reads past the end are clamped to the last entry: the trip body has no branch, which keeps the compiler's wait counts exact)
+    int2 e0 = oc_pair(tab, cb), e1 = oc_pair(tab, cb + 2 * min(1, nst)), e2 = oc_pair(tab, cb + 2 * min(2, nst)), e3 = oc_pair(tab, cb + 2 * min(3, nst));
+    d4 x = oc_ldB(R, e0.x, ln), y = x;
+    d4 a = oc_ldF(BL + (long)e0.y * BLK, ln), c = oc_ldB(R, e1.x, ln);
+    int k = 0;
+#pragma unroll
+    for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
+      if (k + 2 > nst) break;
+      // stage k: y = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
+      const d4 a1 = oc_ldF(BL + (long)e1.y * BLK, ln), c1 = oc_ldB(R, e2.x, ln);
+      const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
+      __builtin_amdgcn_sched_barrier(0);               // the loads above are issued before the multiplies below: a whole stage to land
+      y = oc_mv(a, x, c);
+      oc_stB(R, e1.x, ln, y);
+      // stage k + 1: x = c1 + block(e1.y) y -> position e2.x ; prefetch stage k + 2: block e2.y, rhs of e3.x
+      a = oc_ldF(BL + (long)e2.y * BLK, ln); c = oc_ldB(R, e3.x, ln);
+      __builtin_amdgcn_sched_barrier(0);
+      x = oc_mv(a1, y, c1);
+      oc_stB(R, e2.x, ln, x);
+      e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
     }
-    if (wid == 0 && oc.junc) oc_stB(JUNC, 0, ln, oc_mv(oc_ldF(BL + (long)e.y * BLK, ln), v, d4{0, 0, 0, 0}));
+    if (k < nst) {                                     // odd stage count: one more, result in y
+      y = oc_mv(a, x, c);
+      oc_stB(R, e1.x, ln, y);
+      x = y; e0 = e1;
+    }
+    // x = t of the chain's last position e0.x
+    if (wid == 0 && oc.junc) oc_stB(EXT, 0, ln, oc_mv(oc_ldF(BL + (long)e0.y * BLK, ln), x, d4{0, 0, 0, 0}));
   }
   bsync<NW>();
+  OC_TS(0);
+  if (f >= 0 && wid == (f & (NW - 1))) oc_stB(R, f, ln, oc_ldB(R, f, ln) + oc_ldB(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
   d4 xh = {0, 0, 0, 0};
-  if (oc.has_hub) {
+  if (HUB) {
     // ---- F2
     d4 hacc = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < NG; s++) {
-      const int p = wid + NW * s;
-      if (ow.hub[s] > -2) {
-        d4 t = oc_ldB(R, p, ln);
-        if (p == f) t += oc_ldB(JUNC, 0, ln);
-        if (s < NH && ow.hub[s] == -1) hacc = oc_mv(HF[s < NH ? s : 0], t, hacc);
-        else hacc = oc_mv(oc_ldF(BL + (long)ow.hub[s] * BLK, ln), t, hacc);
-      }
+      const d4 t = oc_ldB(R, ow.vpos[s], ln);
+      if (s < NH) hacc = oc_mv(HF[s < NH ? s : 0], t, hacc);
+      else hacc = oc_mv(oc_ldF(BL + (long)ow.hslot[s] * BLK, ln), t, hacc);
     }
-    oc_stB(HP, wid, ln, hacc);
+    oc_stB(EXT, 1 + wid, ln, hacc);
     bsync<NW>();
     // ---- F3
     d4 th = oc_ldB(R, H, ln);
 #pragma unroll
-    for (int w = 0; w < NW; w++) th += oc_ldB(HP, w, ln);
+    for (int w = 0; w < NW; w++) th += oc_ldB(EXT, 1 + w, ln);
     xh = oc_mv(oc_ldF(BL + (long)oc.ghub_slot * BLK, ln), th, d4{0, 0, 0, 0});
   }
+  OC_TS(1);
   // ---- B1
 #pragma unroll
   for (int s = 0; s < NG; s++) {
-    const int p = wid + NW * s;
-    if (p < oc.nbc) {
-      d4 t = oc_ldB(R, p, ln);
-      if (p == f) t += oc_ldB(JUNC, 0, ln);
-      d4 d = oc_mv(G[s], t, d4{0, 0, 0, 0});
-      if (ow.hub[s] > -2) {
-        if (s < NH && ow.hub[s] == -1) d = oc_mv(HT[s < NH ? s : 0], xh, d);
-        else d = oc_mv(oc_ldT(BL + (long)ow.hub[s] * BLK, ln), xh, d);
-      }
-      oc_stB(R, p, ln, d);
+    const d4 t = oc_ldB(R, ow.vpos[s], ln);
+    d4 d = oc_mv(G[s], t, d4{0, 0, 0, 0});
+    if (HUB) {
+      if (s < NH) d = oc_mv(HT[s < NH ? s : 0], xh, d);
+      else d = oc_mv(oc_ldT(BL + (long)ow.hslot[s] * BLK, ln), xh, d);
     }
+    if (ow.ok[s]) oc_stB(R, ow.vpos[s], ln, d);
   }
   bsync<NW>();
+  OC_TS(2);
   // ---- B2
-  if (oc.has_hub && wid == NW - 1) oc_stB(R, H, ln, xh);     // only now: every wave has read the hub's right-hand side
+  if (HUB && wid == NW - 1) oc_stB(R, H, ln, xh);     // only now: every wave has read the hub's right-hand side
   if (wid < 2 && len > 0) {
+    // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;
-    d4 v;
-    if (wid == 0 && oc.junc) { v = oc_ldB(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
-    else v = oc_ldB(R, oc_tab(tab, cb + 2 * (len - 1)), ln);
+    d4 x;
+    if (wid == 0 && oc.junc) { x = oc_ldB(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
+    else x = oc_ldB(R, tab[cb + 2 * (len - 1)], ln);
     if (k >= 0) {
-      int2 e = oc_pair(tab, cb + 2 * k);             // stage k: x_e.x = d_e.x + block(e.y)' v
-      d4 a = oc_ldT(BL + (long)e.y * BLK, ln), c = oc_ldB(R, e.x, ln);
-      int2 en = k > 0 ? oc_pair(tab, cb + 2 * (k - 1)) : e;
-      for (; k >= 0; k--) {
-        d4 an = a, cn = c; int2 e3 = en;
-        if (k > 0) {
-          an = oc_ldT(BL + (long)en.y * BLK, ln); cn = oc_ldB(R, en.x, ln);
-          if (k > 1) e3 = oc_pair(tab, cb + 2 * (k - 2));
-        }
-        c = oc_mv(a, v, c);
-        oc_stB(R, e.x, ln, c);
-        v = c; e = en; en = e3; a = an; c = cn;
+      int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
+      d4 y = x;
+      d4 a = oc_ldT(BL + (long)e0.y * BLK, ln), c = oc_ldB(R, e0.x, ln);
+#pragma unroll
+      for (int trip = 0; trip < OC_MAXT; trip++) {
+        if (k < 1) break;
+        const d4 a1 = oc_ldT(BL + (long)e1.y * BLK, ln), c1 = oc_ldB(R, e1.x, ln);
+        const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        y = oc_mv(a, x, c);
+        oc_stB(R, e0.x, ln, y);
+        a = oc_ldT(BL + (long)e2.y * BLK, ln); c = oc_ldB(R, e2.x, ln);
+        __builtin_amdgcn_sched_barrier(0);
+        x = oc_mv(a1, y, c1);
+        oc_stB(R, e1.x, ln, x);
+        e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
       }
+      if (k == 0) oc_stB(R, e0.x, ln, oc_mv(a, x, c));
     }
   }
   bsync<NW>();
+#undef OC_TS
 }

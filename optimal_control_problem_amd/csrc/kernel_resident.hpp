@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   constexpr bool OC = OCG > 0;
   static_assert(!OC || (GB && !ZYG && NW == 4), "the on-chip solve is a mode of the 4-wave global-block kernel");
   constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
-  constexpr int EU = 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower)
+  constexpr int EU = OC ? 8 : 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower; the on-chip mode needs the registers)
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (!ok) status = MPCQP_NON_CVX;
   if constexpr (OC) {
     if (ok) {
-      ocw = oc_wave<NW, OCG, OCH>(oc, oc.tab, wid);
+      ocw = oc_wave<NW, OCG, OCH>(oc, oc.tab, wid, npad);
       oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
     }
   }
@@ -739,7 +739,11 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       bsync<NW>();
       TS(4);
       if constexpr (OC) {
-        oc_solve<NW, OCG, OCH>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
+#ifdef MPCQP_TIMING
+        oc_solve<NW, OCG, OCH, true>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+#else
+        oc_solve<NW, OCG, OCH, true>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
+#endif
       } else {
 #ifdef MPCQP_TIMING
         long long *trace = (b == 0 && wid == 0 && iter == 3 && io.dbg) ? io.dbg + 16L * gridDim.x : nullptr;
@@ -786,13 +790,13 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       bsync<NW>();
       TS(6);
       iter_done = iter;
-      if (can_check) {
+      if (__builtin_expect(can_check, 0)) {     // (rare paths are marked cold: their register pressure must not cost the hot loop its registers)
         update_info_res<NW>(cx, in);
         status = check_termination_res<NW>(cx, in, 0);
         TS(7);
         if (status != MPCQP_UNSOLVED) break;
       }
-      if (do_rho) {
+      if (__builtin_expect(do_rho, 0)) {
         if (!can_check) update_info_res<NW>(cx, in);
         const double pr = in.prs / (fmax(in.nzs, in.naxs) + Q_DIV_TOL);
         const double dr = in.drs / (fmax(in.nqs, fmax(in.natys, in.npxs)) + Q_DIV_TOL);

@@ -263,16 +263,11 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       }
     }
     if (h->oc) {
-      // on-chip mode: block tridiagonal (+ arrow) patterns whose factor fits LDS + registers at two workgroups per CU; the largest number
-      // of LDS block slots that keeps the footprint within 80 KB is searched from above
+      // on-chip mode: block tridiagonal + arrow patterns whose factor fits LDS + the registers of the instance at two workgroups per CU
       const ResPlan r4 = build_res_plan(p4, 4, false);
       h->oc = false;
-      const OcPlan all = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();     // every block in LDS: is it this topology at all?
-      for (int nl = all.ok ? all.nlds : 0; nl >= 1; nl--) {
-        const OcPlan o = build_oc_plan(p4, 4, nl, OC_NG, OC_NH);
-        if (!o.ok) break;                                      // would need more register-resident hub blocks than the instance has
-        if (lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) { h->ocplan = o; h->oc = true; break; }
-      }
+      const OcPlan o = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();
+      if (o.ok && lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) { h->ocplan = o; h->oc = true; }
       if (!h->oc && want == 4 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc4")
         return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));
     }

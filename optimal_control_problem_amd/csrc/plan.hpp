@@ -674,7 +674,7 @@ struct OcPlan {
   int nbc = 0, has_hub = 0, junc = 0;
   std::vector<int> chainE, chainF;          // positions in elimination (forward) order
   int npw = 0;                              // positions per wave in the wave-parallel phases: wave w owns p = w + 4 s, s < npw
-  int nhr = 0;                              // hub blocks of the positions with s < nhr live in registers (both layouts), the rest in LDS
+  int nhr = 0;                              // hub blocks of the positions with s < nhr live in registers (both layouts), the rest in LDS; = the instance's OCH
   int nlds = 0;                             // LDS block slots
   std::vector<int> gsrc, csrc, hsrc;        // [nbc] factor block ids (slab order): G_p, W_succ(p),p or -1, W_hub,p or -1
   std::vector<int> cslot, hslot;            // [nbc] LDS slot of the chain / hub block of column p, -1 = none (hub: -1 also when in registers)
@@ -684,7 +684,7 @@ struct OcPlan {
   std::vector<int> tab;
   int o_chainE = 0, o_chainF = 0, o_pos = 0, o_fill = 0;
 };
-constexpr int OC_REXT = 5 * BS;             // behind the solve vector: the junction term and one hub partial sum per wave
+constexpr int OC_REXT = 6 * BS;             // behind the solve vector: the junction term, one hub partial sum per wave, a zero block
 
 inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_npw, int max_nhr) {
   OcPlan oc;
@@ -726,6 +726,7 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
     oc.chainE = c0;
   }
   if ((int)(oc.chainE.size() + oc.chainF.size()) != nbc) return oc;
+  if (oc.chainE.size() > 17 || oc.chainF.size() > 17) return oc;        // the kernel's chain loops are unrolled for 16 stages (OC_MAXT)
   oc.npw = (nbc + nw - 1) / nw;
   if (oc.npw > max_npw) return oc;
   oc.gsrc.assign(nbc, -1); oc.csrc.assign(nbc, -1); oc.hsrc.assign(nbc, -1); oc.cslot.assign(nbc, -1); oc.hslot.assign(nbc, -1);
@@ -736,23 +737,20 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
     if (oc.has_hub) { auto it = bid.find({H, p}); if (it != bid.end()) oc.hsrc[p] = it->second; }
   }
   if (oc.has_hub) { oc.ghub_src = bid.at({H, H}); oc.ghub_slot = slots++; }
-  // hub blocks: LDS while it lasts, filled from the last positions down; the first nhr slots of every wave go to registers
-  oc.nhr = 0;
-  if (oc.has_hub) {
-    while (true) {
-      int need = 0;
-      for (int p = 0; p < nbc; p++) if (oc.hsrc[p] >= 0 && p / nw >= oc.nhr) need++;
-      if (slots + need <= max_lds_blocks) break;
-      if (++oc.nhr > max_nhr) return oc;
-    }
-    for (int p = 0; p < nbc; p++) if (oc.hsrc[p] >= 0 && p / nw >= oc.nhr) oc.hslot[p] = slots++;
-  }
+  // hub blocks: the first nhr slots of every wave in registers -- exactly the kernel instance's count, the loops over a wave's
+  // positions are straight-line code -- the rest in LDS.  The instances in use are built for patterns with an arrow head in which
+  // every column couples to it.
+  if (!oc.has_hub) return oc;
+  for (int p = 0; p < nbc; p++) if (oc.hsrc[p] < 0) return oc;
+  oc.nhr = max_nhr;
+  for (int p = 0; p < nbc; p++) if (p / nw >= oc.nhr) oc.hslot[p] = slots++;
   if (slots > max_lds_blocks) return oc;
   oc.nlds = slots;
   // device table
   oc.tab.push_back((int)oc.chainE.size()); oc.tab.push_back((int)oc.chainF.size());
-  oc.o_chainE = (int)oc.tab.size(); for (int p : oc.chainE) { oc.tab.push_back(p); oc.tab.push_back(oc.cslot[p]); }
-  oc.o_chainF = (int)oc.tab.size(); for (int p : oc.chainF) { oc.tab.push_back(p); oc.tab.push_back(oc.cslot[p]); }
+  // (a chain end without a block below it carries slot 0: the kernel's prefetch reads one stage past the end and drops the result)
+  oc.o_chainE = (int)oc.tab.size(); for (int p : oc.chainE) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
+  oc.o_chainF = (int)oc.tab.size(); for (int p : oc.chainF) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
   oc.o_pos = (int)oc.tab.size();
   for (int p = 0; p < nbc; p++) { int r[5] = {oc.gsrc[p], oc.csrc[p], oc.hsrc[p], oc.cslot[p], oc.hslot[p]}; oc.tab.insert(oc.tab.end(), r, r + 5); }
   oc.o_fill = (int)oc.tab.size();

@@ -26,12 +26,12 @@ L = _lib.lib()
 L.mpcqp_debug_timing.argtypes = [C.c_void_p, C.c_void_p]
 _lib.check(L.mpcqp_debug_timing(qp._h, raw.ctypes.data))
 names = ["load", "ruiz", "apply-scale+init", "factor(first)", "At pass", "schedule(solve)", "A pass + x", "check", "store",
-         "-", "-", "-", "f:rho/dvec/T", "f:assemble", "f:LDL", "f:LDL sweeps"]
+         "oc:F1 chains", "oc:F2+F3 hub", "oc:B1 diag+hub", "f:rho/dvec/T", "f:assemble", "f:LDL", "f:LDL sweeps"]
 tot = out[:, :9].sum(axis=1).mean()
 print("variant", qp.plan_info()["variant"], "kernel %.2f ms for %d QPs, mean iters %.1f, mean cycles/QP %.0f (100 MHz ticks: %s)" % (
     ms, batch, got["iters"].mean(), tot, "s_memtime"))
 for k, nm in enumerate(names):
-    if nm != "-":
+    if nm != "-" and out[:, k].mean() > 0:
         print("  %-20s %10.0f cyc  %5.1f %%" % (nm, out[:, k].mean(), 100 * out[:, k].mean() / tot))
 it = got["iters"].mean()
 print("  per ADMM iteration: At %.0f, solve %.0f, A+x %.0f cycles" % (out[:, 4].mean() / it, out[:, 5].mean() / it, out[:, 6].mean() / it))
