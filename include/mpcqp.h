@@ -76,6 +76,25 @@ int mpcqp_create(int n, int m, int batch,
                  const int *A_colptr, const int *A_rowidx,
                  const mpcqp_settings *settings, mpcqp_handle **out);
 
+/* Opt-in reduced form.  The reference's QP carries variables that are fixed by construction: the parameter block p, whose rows
+ * read p <= p + dp <= p (SQPOptimizationSolver.cpp:47-60,117), and the first frame, pinned through lbx = ubx
+ * (src/OptimalControlProblem.cpp:93-96).  OSQP iterates on them like on any other variable, and so does a handle from
+ * mpcqp_create.  Here the caller names `nfixed` rows of A that have a single entry and l = u in every instance and every
+ * update; their variables are substituted (x_j = l_i / a_ij) before the solve, the remaining QP -- smaller, and without the
+ * parameter block's coupling to every stage -- is solved on its own pattern, and x, y, z are returned in the caller's
+ * dimensions (the multiplier of an eliminated row from stationarity of its variable).  The handle is used like any other
+ * (update / update_vectors / warm_start / set_rho / solve / get; mpcqp_solve_host and mpcqp_debug_scaling are not available).
+ * It is a different, shorter ADMM run on an equivalent QP: x agrees with the full form within the termination tolerance, not
+ * in the last digits, and status / iteration counts / info are the reduced run's (info[0] without the constant the eliminated
+ * variables contribute).  An instance that breaks the promise (l != u on a named row) is refused like one with crossed
+ * bounds (MPCQP_UNSOLVED, NaN).  mpcqp_update_vectors reads the P and A arrays of the last mpcqp_update again (the eliminated
+ * columns enter q, l, u): device pointers borrowed there must still be valid.  The default stays the full form. */
+int mpcqp_create_reduced(int n, int m, int batch,
+                         const int *P_colptr, const int *P_rowidx,
+                         const int *A_colptr, const int *A_rowidx,
+                         int nfixed, const int *fixed_rows,
+                         const mpcqp_settings *settings, mpcqp_handle **out);
+
 /* Replaces CuCaQP::setSystem -> setHessianMatrix/setGradient/setLinearConstraintsMatrix/setLowerBound/
  * setUpperBound (CuCaQP.cpp:43-103,271-288), argument order P,q,A,l,u as at CuCaQP.cpp:283-287.
  * Value arrays are instance-major: QP b reads P + b*strideP (in doubles) ... ; stride 0 shares one array

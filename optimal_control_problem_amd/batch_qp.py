@@ -41,7 +41,9 @@ def _ptr_stride(a, width, batch, name):
 
 
 class BatchQP:
-    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, **kw):
+    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, fixed_rows=None, **kw):
+        """fixed_rows: opt-in reduced form (mpcqp_create_reduced) -- singleton rows of A with l = u in every instance, whose
+        variables are substituted before the solve; None (default) = the full form, what the reference's OSQP solves"""
         self.n, self.m, self.batch = int(n), int(m), int(batch)
         self.Pp = np.ascontiguousarray(Pp, dtype=np.int32); self.Pi = np.ascontiguousarray(Pi, dtype=np.int32)
         self.Ap = np.ascontiguousarray(Ap, dtype=np.int32); self.Ai = np.ascontiguousarray(Ai, dtype=np.int32)
@@ -51,8 +53,13 @@ class BatchQP:
         self._h = C.c_void_p()
         self._keep = []
         L = _lib.lib()
-        _lib.check(L.mpcqp_create(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
-                                  self.Ap.ctypes.data, self.Ai.ctypes.data, C.byref(self.settings), C.byref(self._h)))
+        if fixed_rows is None:
+            _lib.check(L.mpcqp_create(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
+                                      self.Ap.ctypes.data, self.Ai.ctypes.data, C.byref(self.settings), C.byref(self._h)))
+        else:
+            fr = np.ascontiguousarray(fixed_rows, dtype=np.int32)
+            _lib.check(L.mpcqp_create_reduced(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
+                                              self.Ap.ctypes.data, self.Ai.ctypes.data, len(fr), fr.ctypes.data, C.byref(self.settings), C.byref(self._h)))
 
     @property
     def nnzP(self):

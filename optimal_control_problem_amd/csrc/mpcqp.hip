@@ -45,6 +45,7 @@ using namespace mpcqp;
 #include "kernel_onchip.hpp"
 #include "kernel_resident.hpp"
 #include "kernels_util.hpp"
+#include "reduced.hpp"
 
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_last_error;
@@ -98,6 +99,8 @@ struct mpcqp_handle {
   bool have_data = false, solved = false;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // reduced form (mpcqp_create_reduced): this handle keeps the caller's dimensions, `inner` solves the QP without the eliminated variables
+  mpcqp_handle *inner = nullptr; RedMaps red; DevRed dred; double *rx0 = nullptr, *ry0 = nullptr;
 };
 
 template <class T>
@@ -369,6 +372,73 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   return MPCQP_OK;
 }
 
+int mpcqp_create_reduced(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                         int nfixed, const int *fixed_rows, const mpcqp_settings *settings, mpcqp_handle **out) {
+  if (!out) return fail(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n <= 0 || m <= 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai || nfixed < 0 || (nfixed > 0 && !fixed_rows)) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  for (int j = 0; j < n; j++) {
+    if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) return fail(MPCQP_ERR_ARG, "colptr not monotone");
+    for (int k = Pp[j]; k < Pp[j + 1]; k++) if (Pi[k] < 0 || Pi[k] >= n) return fail(MPCQP_ERR_ARG, "P row index out of range");
+    for (int k = Ap[j]; k < Ap[j + 1]; k++) if (Ai[k] < 0 || Ai[k] >= m) return fail(MPCQP_ERR_ARG, "A row index out of range");
+  }
+  RedMaps rm = build_red_maps(n, m, Pp, Pi, Ap, Ai, nfixed, fixed_rows);
+  if (!rm.error.empty()) return fail(MPCQP_ERR_ARG, rm.error);
+  mpcqp_handle *inner = nullptr;
+  int rc = mpcqp_create(rm.nr, rm.mr, batch, rm.Ppr.data(), rm.Pir.data(), rm.Apr.data(), rm.Air.data(), settings, &inner);
+  if (rc) return rc;
+  mpcqp_handle *h = new mpcqp_handle();
+  h->inner = inner; h->st = inner->st; h->device = inner->device; h->n = n; h->m = m; h->batch = batch; h->variant = -1;
+  h->plan.n = n; h->plan.m = m; h->plan.nnzP_in = Pp[n]; h->plan.nnzA_in = Ap[n];
+  h->red = rm;
+  auto bail = [&](int code) { mpcqp_destroy(h); return code; };
+  DevRed &d = h->dred;
+  memset(&d, 0, sizeof(d));
+  d.n = n; d.m = m; d.nr = rm.nr; d.mr = rm.mr; d.nfix = rm.nfix; d.nnzPr = (int)rm.Pir.size(); d.nnzAr = (int)rm.Air.size();
+#define UP(expr) if ((rc = (expr))) return bail(rc)
+  UP(upload(h, rm.Psrc, &d.Psrc)); UP(upload(h, rm.Asrc, &d.Asrc)); UP(upload(h, rm.fix_var, &d.fix_var)); UP(upload(h, rm.fix_row, &d.fix_row));
+  UP(upload(h, rm.fix_src, &d.fix_src)); UP(upload(h, rm.free_var, &d.free_var)); UP(upload(h, rm.kept_row, &d.kept_row));
+  UP(upload(h, rm.var_of, &d.var_of)); UP(upload(h, rm.row_of, &d.row_of));
+  UP(upload(h, rm.qc_ptr, &d.qc_ptr)); UP(upload(h, rm.qc_k, &d.qc_k)); UP(upload(h, rm.qc_src, &d.qc_src));
+  UP(upload(h, rm.lc_ptr, &d.lc_ptr)); UP(upload(h, rm.lc_k, &d.lc_k)); UP(upload(h, rm.lc_src, &d.lc_src));
+  UP(upload(h, rm.yp_ptr, &d.yp_ptr)); UP(upload(h, rm.yp_var, &d.yp_var)); UP(upload(h, rm.yp_src, &d.yp_src));
+  UP(upload(h, rm.ya_ptr, &d.ya_ptr)); UP(upload(h, rm.ya_row, &d.ya_row)); UP(upload(h, rm.ya_src, &d.ya_src));
+  const size_t B = batch;
+  UP(dalloc(h, &d.Pr, B * std::max(d.nnzPr, 1))); UP(dalloc(h, &d.qr, B * rm.nr)); UP(dalloc(h, &d.Ar, B * std::max(d.nnzAr, 1)));
+  UP(dalloc(h, &d.lr, B * std::max(rm.mr, 1))); UP(dalloc(h, &d.ur, B * std::max(rm.mr, 1))); UP(dalloc(h, &d.xfix, B * std::max(rm.nfix, 1)));
+  UP(dalloc(h, &d.bad, B));
+  UP(dalloc(h, &h->ox, B * n)); UP(dalloc(h, &h->oy, B * m)); UP(dalloc(h, &h->oz, B * m));
+  UP(dalloc(h, &h->oinfo, B * 4)); UP(dalloc(h, &h->ostatus, B)); UP(dalloc(h, &h->oiters, B));
+#undef UP
+  memset(&h->io, 0, sizeof(h->io));
+  *out = h;
+  return MPCQP_OK;
+}
+
+// the solve of a reduced handle: substitute the fixed variables, hand the smaller QP to the inner handle, expand its result
+static int solve_reduced(mpcqp_handle *h, hipStream_t s) {
+  mpcqp_handle *in = h->inner; const DevRed &d = h->dred;
+  const bool vectors = h->reuse_next;
+  hipLaunchKernelGGL(mpcqp_presolve_kernel, dim3(h->batch), dim3(256), 0, s, d, h->io, vectors ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  int rc;
+  if (vectors) rc = mpcqp_update_vectors(in, d.qr, d.nr, d.lr, d.mr, d.ur, d.mr, MPCQP_MEM_DEVICE);
+  else rc = mpcqp_update(in, d.Pr, d.nnzPr, d.qr, d.nr, d.Ar, d.nnzAr, d.lr, d.mr, d.ur, d.mr, MPCQP_MEM_DEVICE);
+  if (rc) return rc;
+  if (h->st.warm_start && h->io.x0 && h->io.y0) {
+    if (!h->rx0) { if ((rc = dalloc(h, &h->rx0, (size_t)h->batch * d.nr)) || (rc = dalloc(h, &h->ry0, (size_t)h->batch * std::max(d.mr, 1)))) return rc; }
+    hipLaunchKernelGGL(mpcqp_red_gather_kernel, dim3(h->batch), dim3(256), 0, s, d, h->io.x0, h->io.y0, h->rx0, h->ry0);
+    HIPCHK(hipGetLastError());
+    if ((rc = mpcqp_warm_start(in, h->rx0, h->ry0, MPCQP_MEM_DEVICE))) return rc;
+  }
+  if ((rc = mpcqp_solve(in, (void *)s))) return rc;
+  hipLaunchKernelGGL(mpcqp_postsolve_kernel, dim3(h->batch), dim3(256), 0, s, d, h->io, in->ox, in->oy, in->oz, in->ostatus, in->oiters, in->oinfo,
+                     h->ox, h->oy, h->oz, h->ostatus, h->oiters, h->oinfo);
+  HIPCHK(hipGetLastError());
+  h->last_stream = s; h->solved = true; h->have_factor = h->keep; h->reuse_next = false;
+  return MPCQP_OK;
+}
+
 static int stage(mpcqp_handle *h, double **own, const double *src, long stride, long width, const double **dst, long *dstride) {
   // host-memory update: copy into an owned device buffer
   size_t count = stride == 0 ? (size_t)width : (size_t)stride * (h->batch - 1) + width;
@@ -422,6 +492,7 @@ int mpcqp_warm_start(mpcqp_handle *h, const double *x0, const double *y0, int me
 
 int mpcqp_set_dispatch_hint(mpcqp_handle *h, int enable) {
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (h->inner) return mpcqp_set_dispatch_hint(h->inner, enable);
   h->lpt = enable != 0;
   if (!h->lpt) h->order_cur = -1;
   return MPCQP_OK;
@@ -429,6 +500,13 @@ int mpcqp_set_dispatch_hint(mpcqp_handle *h, int enable) {
 
 int mpcqp_keep_workspace(mpcqp_handle *h, int enable) {
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (h->inner) {
+    const int rc = mpcqp_keep_workspace(h->inner, enable);
+    if (rc) return rc;
+    h->keep = enable != 0;
+    if (!h->keep) { h->have_factor = false; h->reuse_next = false; }
+    return MPCQP_OK;
+  }
   if (enable && h->variant == 0) return fail(MPCQP_ERR_LIMIT, "the streaming kernel variant does not keep its workspace");
   h->keep = enable != 0;
   if (!h->keep) { h->have_factor = false; h->reuse_next = false; }
@@ -458,6 +536,7 @@ int mpcqp_update_vectors(mpcqp_handle *h, const double *q, long sq, const double
 
 int mpcqp_set_rho(mpcqp_handle *h, const double *rho0, int mem) {
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (h->inner) return mpcqp_set_rho(h->inner, rho0, mem);
   HIPCHK(hipSetDevice(h->device));
   if (!rho0) { h->io.rho0 = nullptr; return MPCQP_OK; }
   if (mem == MPCQP_MEM_DEVICE) { h->io.rho0 = rho0; return MPCQP_OK; }
@@ -474,6 +553,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   if (!h->have_data) return fail(MPCQP_ERR_STATE, "Solver not initialized. Call mpcqp_update() first.");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  if (h->inner) return solve_reduced(h, s);
   DevIO io = h->io;
   io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
@@ -536,6 +616,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   if (!h) return fail(MPCQP_ERR_ARG, "null handle");
   if (!q || (h->plan.nnzP_in > 0 && !P) || (h->plan.nnzA_in > 0 && !A) || (h->m > 0 && (!l || !u))) return fail(MPCQP_ERR_ARG, "null data pointer");
   const long wP = h->plan.nnzP_in, wA = h->plan.nnzA_in, n = h->n, m = h->m;
+  if (h->inner) return fail(MPCQP_ERR_STATE, "mpcqp_solve_host is not available on a reduced handle");
   if ((sP && sP != wP) || sq != n || (sA && sA != wA) || (m > 0 && (sl != m || su != m)))
     return fail(MPCQP_ERR_ARG, "dimension mismatch: mpcqp_solve_host takes dense instance-major arrays (stride = width; 0 shares P or A)");
   HIPCHK(hipSetDevice(h->device));
@@ -613,6 +694,7 @@ int mpcqp_sync(mpcqp_handle *h) {
 
 void mpcqp_destroy(mpcqp_handle *h) {
   if (!h) return;
+  if (h->inner) { mpcqp_destroy(h->inner); h->inner = nullptr; }
   (void)hipSetDevice(h->device);
   if (h->solved) (void)hipStreamSynchronize(h->last_stream);
   for (void *p : h->dev_allocs) (void)hipFree(p);
@@ -628,6 +710,7 @@ void mpcqp_destroy(mpcqp_handle *h) {
 int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms) {
   if (!h || !ms) return fail(MPCQP_ERR_ARG, "null pointer");
   if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
+  if (h->inner) return mpcqp_last_kernel_ms(h->inner, ms);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -636,6 +719,7 @@ int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms) {
 
 int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   if (!h || !o) return fail(MPCQP_ERR_ARG, "null pointer");
+  if (h->inner) return mpcqp_plan_info(h->inner, o);        // the plan that runs: the reduced pattern's
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
   o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
@@ -645,6 +729,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
 
 int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c) {
   if (!h || b < 0 || b >= h->batch) return fail(MPCQP_ERR_ARG, "bad instance index");
+  if (h->inner) return fail(MPCQP_ERR_STATE, "scaling of a reduced handle lives in the reduced dimensions");
   if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->last_stream));

@@ -764,3 +764,73 @@ def test_resident_kernel_at_three_and_four_workgroups_per_cu(built, monkeypatch,
     qp.update_vectors(q2, ls.l, ls.u); qp.solve(); g2 = qp.get(); qp.close()
     assert (g2["status"] == r2["status"]).all() and (g2["iters"] == r2["iters"]).all()
     _close(g2, r2, "x")
+
+
+# ---------------------------------------------------------------------------------------------- reduced form (opt-in)
+@pytest.mark.parametrize("name,B,N,first_frame", [("double_integrator", 12, 20, False), ("double_integrator", 12, 20, True), ("quadrotor", 10, 20, False),
+                                                  ("quadrotor", 6, 20, True), ("cartpole", 6, 30, True)])
+def test_reduced_form(built, name, B, N, first_frame):
+    """mpcqp_create_reduced: the parameter rows dp = 0 (reference SQPOptimizationSolver.cpp:117) -- and optionally the pinned first
+    frame (OptimalControlProblem.cpp:93-96) -- named as fixed.  (a) against the oracle on the reduced QP (NumPy statement of the
+    substitution): status, iteration counts, x, y at the tight bar; (b) against the full form: the same optimum within the
+    termination tolerance; (c) the expanded (x, y) satisfy stationarity of the FULL QP as well as the reduced run's dual residual"""
+    from optimal_control_problem_amd.batch_qp import BatchQP, solve_local_system
+    mdl, ls, meta = models.make_workload(name, B, N=N)
+    rows = list(range(mdl.np))
+    if first_frame:
+        rows += [mdl.np + j for j in range(mdl.nx + mdl.nu) if (ls.l[:, mdl.np + j] == ls.u[:, mdl.np + j]).all()]
+        assert len(rows) > mdl.np
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=rows)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get()
+    red, free, kept, fvars, xfix = problems.reduce_qp(ls, rows)
+    assert qp.plan_info()["n"] == red.n and qp.plan_info()["m"] == red.m
+    ref = problems.oracle_solve(red)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    tol = lambda a: 1e-6 * (1.0 + np.abs(a).max())
+    assert np.abs(got["x"][:, free] - ref["x"]).max() <= tol(ref["x"]) and np.abs(got["y"][:, kept] - ref["y"]).max() <= tol(ref["y"])
+    assert np.array_equal(got["x"][:, fvars], xfix) and np.array_equal(got["z"][:, rows], ls.l[:, rows])
+    # (b) the same optimum as the full form: at eps = 1e-3 two ADMM runs on these problems stop far apart in x (both inside the residual
+    # test), so the optimum is compared at a tight tolerance
+    tight = dict(eps_abs=1e-9, eps_rel=1e-9)
+    qt = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=rows, **tight)
+    qt.update(ls.P, ls.q, ls.A, ls.l, ls.u); qt.solve(); gt = qt.get(); qt.close()
+    full = solve_local_system(ls, **tight)
+    assert (full["status"] == 1).all() and (gt["status"] == 1).all()
+    assert np.abs(gt["x"] - full["x"]).max() <= 1e-4 * (1.0 + np.abs(full["x"]).max())
+    assert np.abs(gt["y"] - full["y"]).max() <= 1e-4 * (1.0 + np.abs(full["y"]).max())
+    # (c) the expanded point of the default-tolerance run passes OSQP's residual test on the FULL QP
+    for b in range(B):
+        Pd, Ad = ls.dense(b); Pd = np.triu(Pd) + np.triu(Pd, 1).T
+        x, y, z = got["x"][b], got["y"][b], got["z"][b]
+        stat = Pd @ x + ls.q[b] + Ad.T @ y
+        assert np.abs(stat[fvars]).max() <= 1e-9 * (1.0 + max(np.abs(Pd @ x).max(), np.abs(ls.q[b]).max(), np.abs(Ad.T @ y).max()))   # eliminated variables: exact
+        assert np.abs(stat).max() <= 2 * (1e-3 + 1e-3 * max(np.abs(Pd @ x).max(), np.abs(ls.q[b]).max(), np.abs(Ad.T @ y).max()))
+        assert np.abs(Ad @ x - z).max() <= 2 * (1e-3 + 1e-3 * max(np.abs(Ad @ x).max(), np.abs(z).max()))
+        assert (z >= np.maximum(ls.l[b], -1e30) - 1e-9).all() and (z <= np.minimum(ls.u[b], 1e30) + 1e-9).all()
+    # kept workspace on the reduced handle
+    qp.keep_workspace(True)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); qp.get()
+    q2 = ls.q * 1.1
+    qp.update_vectors(q2, ls.l, ls.u); qp.solve(); b2 = qp.get()
+    red2, *_ = problems.reduce_qp(models.LocalSystem(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P, q2, ls.A, ls.l, ls.u), rows)
+    from oracle import oracle as orc
+    st = orc.State(orc.Pattern(red.n, red.m, red.Pp, red.Pi, red.Ap, red.Ai), B, orc.default_settings())
+    st.solve(red.P, red.q, red.A, red.l, red.u); r2 = st.solve_vectors(red2.q, red2.l, red2.u)
+    assert (b2["iters"] == r2["iters"]).all() and np.abs(b2["x"][:, free] - r2["x"]).max() <= tol(r2["x"])
+    qp.close()
+
+
+def test_reduced_form_refuses_what_it_must(built):
+    from optimal_control_problem_amd import _lib
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, meta = models.make_workload("double_integrator", 4)
+    with pytest.raises(_lib.MpcqpError) as e:
+        BatchQP(ls.n, ls.m, 4, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=[ls.m - 1])       # a dynamics row: more than one entry
+    assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.MpcqpError):
+        BatchQP(ls.n, ls.m, 4, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=[0, 0])
+    qp = BatchQP(ls.n, ls.m, 4, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=list(range(mdl.np)))
+    l = ls.l.copy(); l[2, 0] -= 0.5                                                   # instance 2 breaks the promise l = u on a named row
+    qp.update(ls.P, ls.q, ls.A, l, ls.u); qp.solve(); got = qp.get()
+    assert got["status"][2] == 11 and np.isnan(got["x"][2]).all() and (np.delete(got["status"], 2) == 1).all()
+    qp.close()
