@@ -71,6 +71,7 @@ def main():
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
     ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4", "oc4"])
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 flow on a one-GPU box: all ranks use cuda:0, collectives over gloo")
+    ap.add_argument("--reduced", action="store_true", help="opt-in reduced form (mpcqp_create_reduced): the parameter rows dp = 0 named as fixed; not the headline configuration")
     ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
     args = ap.parse_args()
 
@@ -112,6 +113,8 @@ def main():
     kw = dict(device=local)
     if args.force_iters:
         kw.update(max_iter=args.force_iters, eps_abs=0.0, eps_rel=0.0, eps_prim_inf=0.0, eps_dual_inf=0.0, adaptive_rho=0)
+    if args.reduced:
+        kw["fixed_rows"] = list(range(mdl.np))
     qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, **kw)
     # `value` is measured with the instances handed to workgroups in batch order.  The longest-first dispatch hint
     # (mpcqp_set_dispatch_hint, on by default in the library) predicts from the previous solve of the same handle; this
@@ -172,7 +175,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s nx=%d nu=%d horizon=%d, reference formulation n=%d m=%d, batch=%d per GPU, "
-                                   "eps_abs=eps_rel=1e-3, cold start" % (mdl.name, mdl.nx, mdl.nu, N, ls.n, ls.m, batch),
+                                   "eps_abs=eps_rel=1e-3, cold start%s" % (mdl.name, mdl.nx, mdl.nu, N, ls.n, ls.m, batch, ", REDUCED FORM (opt-in: parameter rows eliminated)" if args.reduced else ""),
                        "batch_per_gpu": batch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "dispatch": "batch order (the longest-first hint from the previous solve's iteration counts is off for `value`; see with_dispatch_hint)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -211,6 +214,28 @@ def main():
             out["with_dispatch_hint"] = {"value": batch / tn, "unit": "QP solves/s", "ms_per_step": tn * 1e3,
                                          "note": "mpcqp_set_dispatch_hint(h, 1) (library default): longest-first from the previous solve's iteration counts; exact predictor on a repeated batch"}
             qp.set_dispatch_hint(False)
+            # the opt-in reduced form on the same batch (mpcqp_create_reduced: the rows dp = 0 named as fixed -> no parameter block, no arrow in the
+            # KKT matrix): an equivalent QP, a different ADMM run -- reported beside `value`, never as `value`
+            try:
+                qr_ = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=list(range(mdl.np)), device=local)
+                qr_.set_dispatch_hint(False)
+                rit = torch.empty(batch, dtype=torch.int32, device=dev)
+                def rstep():
+                    qr_.update(dP, dq, dA, dl, du); qr_.solve(stream); qr_.get_device(x=ox, y=oy, status=ost, iters=rit)
+                for _ in range(2):
+                    rstep()
+                torch.cuda.synchronize(); tr = time.perf_counter()
+                for _ in range(5):
+                    rstep()
+                torch.cuda.synchronize(); tr = (time.perf_counter() - tr) / 5
+                out["reduced_form"] = {"value": batch / tr, "unit": "QP solves/s", "ms_per_step": tr * 1e3, "kernel_ms": qr_.last_kernel_ms(), "variant": qr_.plan_info()["variant"],
+                                       "mean_admm_iters": float(rit.float().mean()), "solved_frac": float((ost == 1).float().mean()),
+                                       "note": "opt-in: variables fixed by equality singleton rows (the parameter block, dp = 0) substituted before the solve; presolve + solve + postsolve in the step"}
+                qr_.close()
+                step()      # restore ox / oy / ost of the full form for the legs below
+                torch.cuda.synchronize()
+            except Exception as e:
+                out["reduced_form"] = {"error": repr(e)}
             # the same step with the boundary handing over HOST buffers (what a CuCaQP-style caller does: pageable inputs in,
             # x / status / iters out): H2D + kernel + D2H per step.  Reported beside `value`, never as `value`.
             hx = np.empty((batch, ls.n)); hst = np.empty(batch, np.int32); hit = np.empty(batch, np.int32)

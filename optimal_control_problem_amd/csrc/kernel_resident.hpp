@@ -740,9 +740,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        oc_solve<NW, OCG, OCH, true>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
 #else
-        oc_solve<NW, OCG, OCH, true>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
 #endif
       } else {
 #ifdef MPCQP_TIMING

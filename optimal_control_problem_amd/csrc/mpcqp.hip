@@ -139,7 +139,7 @@ constexpr long OC_LDS_MAX = 80 * 1024;      // two workgroups per CU
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
-  if (h->oc) return (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH>;
+  if (h->oc) return h->ocplan.has_hub ? (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, 0>;
   if (h->gblocks && h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, true, REUSE>;
   if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
   if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;

@@ -695,14 +695,14 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
   const int H = nb - 1;
   // is the last block an arrow head?  It is when some column has it beside a chain successor; a last block that only its neighbour
   // couples to is the end of the chain
-  int hub_cols = 0, hub_with_chain = 0;
+  int hub_with_chain = 0;
   for (int p = 0; p < H; p++) {
     const std::vector<int> &rows = pl.colrows[p];
     const bool hh = std::find(rows.begin(), rows.end(), H) != rows.end();
     if ((int)rows.size() - (hh ? 1 : 0) > 1) return oc;                 // more than one chain successor: not this topology
-    if (hh) { hub_cols++; if (rows.size() > 1) hub_with_chain++; }
+    if (hh && rows.size() > 1) hub_with_chain++;
   }
-  oc.has_hub = hub_with_chain > 0 || hub_cols > 1;
+  oc.has_hub = hub_with_chain > 0;          // (a last block that is only ever a column's single neighbour is a chain end -- in the twisted order of both chains)
   oc.nbc = oc.has_hub ? nb - 1 : nb;
   const int nbc = oc.nbc;
   std::vector<int> succ(nbc, -1), npred(nbc, 0);
@@ -738,12 +738,14 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
   }
   if (oc.has_hub) { oc.ghub_src = bid.at({H, H}); oc.ghub_slot = slots++; }
   // hub blocks: the first nhr slots of every wave in registers -- exactly the kernel instance's count, the loops over a wave's
-  // positions are straight-line code -- the rest in LDS.  The instances in use are built for patterns with an arrow head in which
-  // every column couples to it.
-  if (!oc.has_hub) return oc;
-  for (int p = 0; p < nbc; p++) if (oc.hsrc[p] < 0) return oc;
-  oc.nhr = max_nhr;
-  for (int p = 0; p < nbc; p++) if (p / nw >= oc.nhr) oc.hslot[p] = slots++;
+  // positions are straight-line code -- the rest in LDS.  The instances in use: patterns with an arrow head to which every column
+  // couples (max_nhr register-resident hub blocks per wave), and patterns without one (the reduced form, no parameters).
+  oc.nhr = 0;
+  if (oc.has_hub) {
+    for (int p = 0; p < nbc; p++) if (oc.hsrc[p] < 0) return oc;
+    oc.nhr = max_nhr;
+    for (int p = 0; p < nbc; p++) if (p / nw >= oc.nhr) oc.hslot[p] = slots++;
+  }
   if (slots > max_lds_blocks) return oc;
   oc.nlds = slots;
   // device table

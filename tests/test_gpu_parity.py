@@ -341,6 +341,24 @@ def test_onchip_variant_vs_oracle(built, monkeypatch, name, batch, N):
         _close(got, ref, k)
 
 
+@pytest.mark.parametrize("name,B,N", [("quadrotor", 9, 20), ("cartpole", 5, 40)])
+def test_onchip_variant_without_hub(built, monkeypatch, name, B, N):
+    """the reduced form has no parameter block, so its pattern is block tridiagonal without an arrow head: the on-chip instance
+    without hub phases (chains, diagonal, chains), against the oracle on the reduced QP"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "oc4")
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    rows = list(range(mdl.np))
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=rows)
+    assert qp.plan_info()["variant"] == 204
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    red, free, kept, fvars, xfix = problems.reduce_qp(ls, rows)
+    ref = problems.oracle_solve(red)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    assert np.abs(got["x"][:, free] - ref["x"]).max() <= 1e-6 * (1.0 + np.abs(ref["x"]).max())
+    assert np.abs(got["y"][:, kept] - ref["y"]).max() <= 1e-6 * (1.0 + np.abs(ref["y"]).max())
+
+
 def test_onchip_is_the_default_for_the_north_star_size(built):
     from optimal_control_problem_amd.batch_qp import BatchQP
     mdl, ls, _ = models.make_workload("quadrotor", 2, N=20)
