@@ -410,7 +410,25 @@ def trace_cost(lfun, nx, nu, nr):
     return tape, gradient_tape(tape)
 
 
-def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None):
+def _trace_link(kfun, nx, nu, nk):
+    """kfun(s, u, s_next, u_next) -> [..., nk] on tracers over the inputs [s; u; s_next; u_next]"""
+    tape = Tape(2 * (nx + nu))
+    mk = lambda a, b: TV(tape, [TS(tape, i) for i in range(a, b)])
+    f = nx + nu
+    out = kfun(mk(0, nx), mk(nx, f), mk(f, f + nx), mk(f + nx, 2 * f))
+    if isinstance(out, TS):
+        out = TV(tape, [out])
+    if isinstance(out, (list, tuple)):
+        out = TV(tape, [TS._lift(tape, v) for v in out])
+    if not isinstance(out, TV) or len(out) != nk:
+        raise ValueError("kfun must return the link-constraint values, %d components" % nk)
+    tape.outputs = [TS._lift(tape, v).idx for v in out.items]
+    tape.nx, tape.nu = nx, nu
+    tape.in_names = [("s", nx), ("u", nu), ("sn", nx), ("un", nu)]
+    return tape
+
+
+def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None, kfun=None, nk=0, k_lo=None, k_hi=None):
     """Run F (and the optional per-stage path constraint hfun) once on tracers.  F(s, u) -> s_next with s [..., nx],
     u [..., nu] (the contract of models.StageOCP.F); hfun(s, u) -> [..., nh] with bounds h_lo <= hfun <= h_hi.
     lcost(s, u, r) -> scalar: a general stage cost summed over the frames (r = the reference parameter, size nx), replacing
@@ -423,6 +441,13 @@ def trace(F, nx, nu, hfun=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=No
         tape.path = _trace_fn(hfun, nx, nu, tape.nh, "hfun must return the path-constraint values")
         tape.h_lo = [float(v) for v in np.broadcast_to(np.asarray(h_lo, float), (tape.nh,))]
         tape.h_hi = [float(v) for v in np.broadcast_to(np.asarray(h_hi, float), (tape.nh,))]
+    # link constraint k_lo <= kfun(s_k, u_k, s_{k+1}, u_{k+1}) <= k_hi between consecutive frames (rate limits and the like)
+    tape.nk = int(nk) if kfun is not None else 0
+    tape.link = None
+    if tape.nk:
+        tape.link = _trace_link(kfun, nx, nu, tape.nk)
+        tape.k_lo = [float(v) for v in np.broadcast_to(np.asarray(k_lo, float), (tape.nk,))]
+        tape.k_hi = [float(v) for v in np.broadcast_to(np.asarray(k_hi, float), (tape.nk,))]
     tape.cost = None
     if lcost is not None:
         L, G = trace_cost(lcost, nx, nu, nx)
@@ -454,7 +479,14 @@ def _emit_body(tape):
         nd = tape.nodes[i]
         if nd[0] == "in":
             nu = getattr(tape, "nu", tape.n_in - nx)
-            ref[i] = "s[%d]" % nd[1] if nd[1] < nx else "u[%d]" % (nd[1] - nx) if nd[1] < nx + nu else "r[%d]" % (nd[1] - nx - nu)
+            if getattr(tape, "in_names", None):
+                k = nd[1]
+                for nm, cnt in tape.in_names:
+                    if k < cnt:
+                        ref[i] = "%s[%d]" % (nm, k); break
+                    k -= cnt
+            else:
+                ref[i] = "s[%d]" % nd[1] if nd[1] < nx else "u[%d]" % (nd[1] - nx) if nd[1] < nx + nu else "r[%d]" % (nd[1] - nx - nu)
         elif nd[0] == "const":
             ref[i] = _lit(nd[1])
         elif nd[0] in _UNARY:
@@ -476,12 +508,15 @@ def _blit(v):
 def emit_functor(tape, name="SmUser"):
     """C++ source of the functor (same shape as the zoo's functors in csrc/stage_models.hpp)"""
     nh = getattr(tape, "nh", 0)
+    nk = getattr(tape, "nk", 0)
     cost = getattr(tape, "cost", None)
     hbody = _emit_body(tape.path) if nh else ""
-    src = ("struct %s {\n  static constexpr int nx = %d, nu = %d, nh = %d, has_cost = %d, has_term = %d;\n"
+    kbody = _emit_body(tape.link) if nk else ""
+    src = ("struct %s {\n  static constexpr int nx = %d, nu = %d, nh = %d, nk = %d, has_cost = %d, has_term = %d;\n"
            "  template <class T> SM_HD static void F(const double *, double, const T *s, const T *u, T *out) {\n%s\n  }\n"
            "  template <class T> SM_HD static void H(const T *s, const T *u, T *out) {\n%s\n  }\n"
-           % (name, tape.nx, tape.nu, nh, 1 if cost else 0, 1 if cost and cost["LT"] is not None else 0, _emit_body(tape), hbody))
+           "  template <class T> SM_HD static void K(const T *s, const T *u, const T *sn, const T *un, T *out) {\n%s\n  }\n"
+           % (name, tape.nx, tape.nu, nh, nk, 1 if cost else 0, 1 if cost and cost["LT"] is not None else 0, _emit_body(tape), hbody, kbody))
     if cost:
         # L: out[0] = l(s, u, r); LG: out[nx + nu + nx] = dl / d[s; u; r]; LT, LTG: the terminal frame's
         for fn, tp in (("L", cost["L"]), ("LG", cost["G"]), ("LT", cost["LT"] or cost["L"]), ("LTG", cost["GT"] or cost["G"])):
@@ -490,6 +525,9 @@ def emit_functor(tape, name="SmUser"):
     lo = ", ".join(_blit(v) for v in tape.h_lo) if nh else "0.0"
     hi = ", ".join(_blit(v) for v in tape.h_hi) if nh else "0.0"
     src += "static const double %s_h_lo[] = {%s};\nstatic const double %s_h_hi[] = {%s};\n" % (name, lo, name, hi)
+    klo = ", ".join(_blit(v) for v in tape.k_lo) if nk else "0.0"
+    khi = ", ".join(_blit(v) for v in tape.k_hi) if nk else "0.0"
+    src += "static const double %s_k_lo[] = {%s};\nstatic const double %s_k_hi[] = {%s};\n" % (name, klo, name, khi)
     mk = ", ".join(str(int(v)) for v in cost["mask"].ravel()) if cost else "0"
     src += "static const unsigned char %s_cost_mask[] = {%s};\n" % (name, mk)
     return src
@@ -504,6 +542,8 @@ int mpcqp_user_abi() { return STAGE_ABI_VERSION; }
 void mpcqp_user_dims(int *nx, int *nu) { *nx = SmUser::nx; *nu = SmUser::nu; }
 int mpcqp_user_nh() { return SmUser::nh; }
 void mpcqp_user_path_bounds(double *lo, double *hi) { for (int i = 0; i < SmUser::nh; i++) { lo[i] = SmUser_h_lo[i]; hi[i] = SmUser_h_hi[i]; } }
+int mpcqp_user_nk() { return SmUser::nk; }
+void mpcqp_user_link_bounds(double *lo, double *hi) { for (int i = 0; i < SmUser::nk; i++) { lo[i] = SmUser_k_lo[i]; hi[i] = SmUser_k_hi[i]; } }
 // general stage cost: 1 and the Hessian's structure over [s; u; r] (row-major (f + nx)^2 bytes), or 0 for diagonal tracking weights
 int mpcqp_user_cost(unsigned char *mask) {
   if (!SmUser::has_cost) return 0;
@@ -557,6 +597,20 @@ void user_host_eval(const double *s, const double *u, double *out, double *jac) 
   }
 }
 int user_host_nh() { return SmUser::nh; }
+int user_host_nk() { return SmUser::nk; }
+// out [nk], jac [nk * 2 (nx + nu)] row-major over [s; u; s_next; u_next]
+void user_host_link(const double *s, const double *u, const double *sn, const double *un, double *out, double *jac) {
+  constexpr int nx = SmUser::nx, nu = SmUser::nu, f = nx + nu, nk = SmUser::nk;
+  if constexpr (nk > 0) {
+    for (int c = 0; c < 2 * f; c++) {
+      Dual sd[nx], ud[nu], snd[nx], und[nu], od[nk];
+      for (int i = 0; i < nx; i++) { sd[i] = {s[i], i == c ? 1.0 : 0.0}; snd[i] = {sn[i], f + i == c ? 1.0 : 0.0}; }
+      for (int i = 0; i < nu; i++) { ud[i] = {u[i], nx + i == c ? 1.0 : 0.0}; und[i] = {un[i], f + nx + i == c ? 1.0 : 0.0}; }
+      SmUser::K<Dual>(sd, ud, snd, und, od);
+      for (int r = 0; r < nk; r++) { jac[r * 2 * f + c] = od[r].d; out[r] = od[r].v; }
+    }
+  }
+}
 int user_host_has_cost() { return SmUser::has_cost; }
 void user_host_cost(const double *s, const double *u, const double *r, int term, double *val, double *grad, double *hess) {
   host_cost<SmUser>(s, u, r, term, val, grad, hess);

@@ -88,19 +88,20 @@ int mpcqp_stage_default(int model, int horizon, mpcqp_stage_desc *d) {
 }
 
 static int stage_create_common(const mpcqp_stage_desc *d, int nx, int nu, int nh, const double *h_lo, const double *h_hi, mpcqp_stage *s,
-                               const unsigned char *cost_mask = nullptr) {
+                               const unsigned char *cost_mask = nullptr, int nk = 0, const double *k_lo = nullptr, const double *k_hi = nullptr) {
   int dev = 0;
   if (int rc = mpcqp_pick_device(d->device, &dev)) return rc;
   s->desc = *d; s->device = dev;
   StageDev &sd = s->sd;
   sd.model = d->model; sd.N = d->horizon; sd.dt = d->dt; sd.nx = nx; sd.nu = nu;
   sd.f = sd.nx + sd.nu; sd.np = sd.nx; sd.nvar = sd.N * sd.f; sd.n = sd.np + sd.nvar;
-  sd.nh = nh; sd.ngd = (sd.N - 1) * sd.nx; sd.ng = sd.ngd + sd.N * nh; sd.m = sd.n + sd.ng;
+  sd.nh = nh; sd.nk = nk; sd.ngd = (sd.N - 1) * sd.nx; sd.ng = sd.ngd + sd.N * nh + (sd.N - 1) * nk; sd.m = sd.n + sd.ng;
+  for (int i = 0; i < SM_MAXNK; i++) { sd.k_lo[i] = (k_lo && i < nk) ? k_lo[i] : -INFINITY; sd.k_hi[i] = (k_hi && i < nk) ? k_hi[i] : INFINITY; }
   for (int i = 0; i < SM_MAXNH; i++) { sd.h_lo[i] = (h_lo && i < nh) ? h_lo[i] : -INFINITY; sd.h_hi[i] = (h_hi && i < nh) ? h_hi[i] : INFINITY; }
   for (int i = 0; i < SM_MAXNX; i++) sd.Q[i] = d->Q[i];
   for (int i = 0; i < SM_MAXNU; i++) sd.R[i] = d->R[i];
   for (int i = 0; i < SM_NPAR; i++) sd.par[i] = d->par[i];
-  sm_build_pattern(sd.nx, sd.nu, sd.N, sd.nh, s->Pp, s->Pi, s->Ap, s->Ai);
+  sm_build_pattern(sd.nx, sd.nu, sd.N, sd.nh, sd.nk, s->Pp, s->Pi, s->Ap, s->Ai);
   if (cost_mask) sm_build_cost_pattern(sd.nx, sd.nu, sd.N, cost_mask, s->Pp, s->Pi);
   sd.nnzP = (int)s->Pi.size(); sd.nnzA = (int)s->Ai.size();
   if (hipSetDevice(dev) != hipSuccess) return mpcqp_set_error(MPCQP_ERR_HIP, "hipSetDevice failed");
@@ -157,13 +158,20 @@ int mpcqp_stage_create_user(const mpcqp_stage_desc *d, const char *library_path,
   }
   double h_lo[SM_MAXNH], h_hi[SM_MAXNH];
   if (nh > 0) hb(h_lo, h_hi);
+  int nk = 0;
+  auto nkf = (int (*)())dlsym(lib, "mpcqp_user_nk");
+  auto kb = (void (*)(double *, double *))dlsym(lib, "mpcqp_user_link_bounds");
+  if (nkf) nk = nkf();
+  if (nk < 0 || nk > SM_MAXNK || (nk > 0 && !kb)) { dlclose(lib); return mpcqp_set_error(MPCQP_ERR_LIMIT, "the link constraint may have 0..8 rows"); }
+  double k_lo[SM_MAXNK], k_hi[SM_MAXNK];
+  if (nk > 0) kb(k_lo, k_hi);
   mpcqp_stage *s = new mpcqp_stage();
   s->user_lib = lib; s->user_eval = ev; s->user_merit = me;
   mpcqp_stage_desc dd = *d; dd.model = MPCQP_MODEL_USER;
   std::vector<unsigned char> mask((size_t)(2 * nx + nu) * (2 * nx + nu));
   auto cf = (int (*)(unsigned char *))dlsym(lib, "mpcqp_user_cost");
   s->general_cost = cf && cf(mask.data());
-  if (int rc = stage_create_common(&dd, nx, nu, nh, h_lo, h_hi, s, s->general_cost ? mask.data() : nullptr)) { mpcqp_stage_destroy(s); return rc; }
+  if (int rc = stage_create_common(&dd, nx, nu, nh, h_lo, h_hi, s, s->general_cost ? mask.data() : nullptr, nk, k_lo, k_hi)) { mpcqp_stage_destroy(s); return rc; }
   *out = s;
   return MPCQP_OK;
 }

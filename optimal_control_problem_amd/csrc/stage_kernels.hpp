@@ -7,12 +7,13 @@
 #include <hip/hip_runtime.h>
 #include "stage_models.hpp"
 
-#define STAGE_ABI_VERSION 5
+#define STAGE_ABI_VERSION 6
 
 struct StageDev {
-  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows
-  int nh, ngd;
+  int model, N, nx, nu, f, np, n, m, ng, nvar, nnzP, nnzA;   // ng = all general rows: (N-1)*nx dynamics rows, then N*nh path rows, then (N-1)*nk link rows
+  int nh, ngd, nk;
   double h_lo[SM_MAXNH], h_hi[SM_MAXNH];   // path-constraint bounds, for the merit kernel's violation measure
+  double k_lo[SM_MAXNK], k_hi[SM_MAXNK];   // link-constraint bounds (the same on every stage), likewise
   double dt;
   double Q[SM_MAXNX], R[SM_MAXNU], par[SM_NPAR];
   const int *Pp, *Ap;   // device copies of the column pointers
@@ -144,12 +145,48 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
     M::template H<Dual>(s, uu, hv);
 #pragma unroll
     for (int r = 0; r < nh; r++) Ac[a + r] = hv[r].d;
+    a += nh;
     for (int r0 = c; r0 < nh; r0 += f) {      // nh may exceed the frame size: lane c takes rows c, c + f, ...
       double hc = 0.0;
 #pragma unroll
       for (int r = 0; r < nh; r++) hc = r == r0 ? hv[r].v : hc;
       const int row = n + sd.ngd + k * nh + r0; const long gi = (long)b * sd.ng + sd.ngd + k * nh + r0;
       lb[row] = lbg[gi] - hc; ub[row] = ubg[gi] - hc;
+    }
+  }
+  if constexpr (M::nk > 0) {
+    // link constraint r_k = K(frame_k, frame_{k+1}) (rate limits u_{k+1} - u_k and the like): this column takes part in r_{k-1} as
+    // the second frame and in r_k as the first; lane c < nk of frame k < N - 1 also owns the shifted bounds of row r_k[c]
+    constexpr int nk = M::nk;
+    const int g0 = sd.ngd + N * sd.nh;
+    Dual os[nx], ou[nu], kv[nk];
+    if (k >= 1) {
+      const double *pf = fr - f;
+#pragma unroll
+      for (int i = 0; i < nx; i++) os[i] = {pf[i], 0.0};
+#pragma unroll
+      for (int i = 0; i < nu; i++) ou[i] = {pf[nx + i], 0.0};
+      M::template K<Dual>(os, ou, s, uu, kv);
+#pragma unroll
+      for (int r = 0; r < nk; r++) Ac[a + r] = kv[r].d;
+      a += nk;
+    }
+    if (k < N - 1) {
+      const double *nf = fr + f;
+#pragma unroll
+      for (int i = 0; i < nx; i++) os[i] = {nf[i], 0.0};
+#pragma unroll
+      for (int i = 0; i < nu; i++) ou[i] = {nf[nx + i], 0.0};
+      M::template K<Dual>(s, uu, os, ou, kv);
+#pragma unroll
+      for (int r = 0; r < nk; r++) Ac[a + r] = kv[r].d;
+      for (int r0 = c; r0 < nk; r0 += f) {
+        double kc = 0.0;
+#pragma unroll
+        for (int r = 0; r < nk; r++) kc = r == r0 ? kv[r].v : kc;
+        const int row = n + g0 + k * nk + r0; const long gi = (long)b * sd.ng + g0 + k * nk + r0;
+        lb[row] = lbg[gi] - kc; ub[row] = ubg[gi] - kc;
+      }
     }
   }
 }
@@ -195,6 +232,18 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
       for (int i = 0; i < M::nh; i++) {
         const double lo = sd.h_lok ? sd.h_lok[k * M::nh + i] : sd.h_lo[i], hi = sd.h_hik ? sd.h_hik[k * M::nh + i] : sd.h_hi[i];
         gmax = fmax(gmax, fmax(lo - hv[i], hv[i] - hi));
+      }
+    }
+    if constexpr (M::nk > 0) {
+      if (k < sd.N - 1) {
+        double ns[nx], nun[nu], kv[M::nk];
+#pragma unroll
+        for (int i = 0; i < nx; i++) ns[i] = fr[f + i];
+#pragma unroll
+        for (int i = 0; i < nu; i++) nun[i] = fr[f + nx + i];
+        M::template K<double>(s, uu, ns, nun, kv);
+#pragma unroll
+        for (int i = 0; i < M::nk; i++) gmax = fmax(gmax, fmax(sd.k_lo[i] - kv[i], kv[i] - sd.k_hi[i]));
       }
     }
   }

@@ -51,7 +51,7 @@ SM_HD double sm_der(double) { return 0.0; }
 SM_HD double sm_der(Dual a) { return a.d; }
 
 enum { SM_DOUBLE_INTEGRATOR = 0, SM_QUADROTOR = 1, SM_CARTPOLE = 2, SM_NMODELS = 3 };
-constexpr int SM_MAXNX = 16, SM_MAXNU = 8, SM_NPAR = 8, SM_MAXNH = 16;
+constexpr int SM_MAXNX = 16, SM_MAXNU = 8, SM_NPAR = 8, SM_MAXNH = 16, SM_MAXNK = 8;
 
 // continuous dynamics + RK4 over dt (models.py StageOCP.F); models with a closed-form discrete map override F
 template <class M, class T>
@@ -74,7 +74,7 @@ SM_HD void sm_rk4(const double *par, double h, const T *s, const T *u, T *out) {
 
 // nx = 2, nu = 1; exact zero-order-hold map (models.py DoubleIntegrator.F); no parameters
 struct SmDoubleIntegrator {
-  static constexpr int nx = 2, nu = 1, nh = 0, has_cost = 0, has_term = 0;
+  static constexpr int nx = 2, nu = 1, nh = 0, nk = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void F(const double *, double h, const T *s, const T *u, T *out) {
     out[0] = s[0] + h * s[1] + ((0.5 * h) * h) * u[0];
@@ -84,7 +84,7 @@ struct SmDoubleIntegrator {
 
 // 12-state quadrotor (models.py Quadrotor.cdyn); par = {mass, grav, arm, kappa, Jx, Jy, Jz}
 struct SmQuadrotor {
-  static constexpr int nx = 12, nu = 4, nh = 0, has_cost = 0, has_term = 0;
+  static constexpr int nx = 12, nu = 4, nh = 0, nk = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
     const double mass = par[0], grav = par[1], arm = par[2], kappa = par[3], Jx = par[4], Jy = par[5], Jz = par[6];
@@ -110,7 +110,7 @@ struct SmQuadrotor {
 
 // cart-pole, s = [x, theta, xdot, thetadot], theta = 0 upright (models.py CartPole.cdyn); par = {mc, mp, length, grav}
 struct SmCartPole {
-  static constexpr int nx = 4, nu = 1, nh = 0, has_cost = 0, has_term = 0;
+  static constexpr int nx = 4, nu = 1, nh = 0, nk = 0, has_cost = 0, has_term = 0;
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
   template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
     const double mc = par[0], mp = par[1], len = par[2], grav = par[3];
@@ -139,8 +139,9 @@ inline void sm_model_dims(int model, int *nx, int *nu) {
 // reference src/sqp_solver/SQPOptimizationSolver.cpp:47-77), rows ascending inside a column:
 //   P column p_i: rows p_i, s_0[i] .. s_{N-1}[i];  column s_k[i]: rows p_i, s_k[i];  column u_k[i]: row u_k[i]
 //   A column j: row j; for a state column of frame k >= 1 the +1 of s_k in g_{k-1}[c]; for k < N-1 the nx rows of g_k;
-//   then the nh path-constraint rows of frame k (rows [p; x; g; h], h_k behind all dynamics rows)
-inline void sm_build_pattern(int nx, int nu, int N, int nh, std::vector<int> &Pp, std::vector<int> &Pi, std::vector<int> &Ap, std::vector<int> &Ai) {
+//   then the nh path-constraint rows of frame k (rows [p; x; g; h; r], h_k behind all dynamics rows), then the nk link-constraint
+//   rows r_{k-1} and r_k this frame takes part in (r_k = K(frame_k, frame_{k+1}), k < N - 1, behind all path rows)
+inline void sm_build_pattern(int nx, int nu, int N, int nh, int nk, std::vector<int> &Pp, std::vector<int> &Pi, std::vector<int> &Ap, std::vector<int> &Ai) {
   const int f = nx + nu, np = nx, n = np + N * f;
   Pp.assign(1, 0); Ap.assign(1, 0); Pi.clear(); Ai.clear();
   for (int i = 0; i < np; i++) {
@@ -159,6 +160,8 @@ inline void sm_build_pattern(int nx, int nu, int N, int nh, std::vector<int> &Pp
       if (k >= 1 && c < nx) Ai.push_back(n + (k - 1) * nx + c);
       if (k < N - 1) for (int r = 0; r < nx; r++) Ai.push_back(n + k * nx + r);
       for (int r = 0; r < nh; r++) Ai.push_back(n + (N - 1) * nx + k * nh + r);
+      if (k >= 1) for (int r = 0; r < nk; r++) Ai.push_back(n + (N - 1) * nx + N * nh + (k - 1) * nk + r);
+      if (k < N - 1) for (int r = 0; r < nk; r++) Ai.push_back(n + (N - 1) * nx + N * nh + k * nk + r);
       Ap.push_back((int)Ai.size());
     }
 }

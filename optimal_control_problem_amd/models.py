@@ -148,6 +148,37 @@ class StageOCP:
     # src/OptimalControlProblem.cpp:448-470); rows are stacked behind the dynamics rows: c = [p; x; g; h].  h_lo, h_hi: [nh] for
     # every frame, or [N, nh] when they differ by frame (a terminal constraint is loose, -inf / +inf, on every frame but the last)
     nh = 0; h_lo = None; h_hi = None
+    # optional link constraint between consecutive frames, k_lo <= kfun(s_k, u_k, s_{k+1}, u_{k+1}) <= k_hi, nk rows per stage
+    # k = 0 .. N-2 (rate limits u_{k+1} - u_k and the like; in the reference any SX over the whole decision vector can be a
+    # constraint, src/OptimalControlProblem.cpp:448-489); rows behind the path rows: c = [p; x; g; h; r]
+    nk = 0; k_lo = None; k_hi = None
+
+    def kfun(self, s, u, sn, un):
+        """[..., nk] link-constraint values; must accept complex input (override together with nk, k_lo, k_hi)"""
+        raise NotImplementedError
+
+    def link_bounds(self):
+        """([N-1, nk], [N-1, nk]) bounds of the link constraint per stage (the same on every stage)"""
+        return (np.broadcast_to(np.asarray(self.k_lo, float), (self.N - 1, self.nk)).copy(),
+                np.broadcast_to(np.asarray(self.k_hi, float), (self.N - 1, self.nk)).copy())
+
+    def dk(self, s, u, sn, un):
+        """[..., nk, 2 f] Jacobian of kfun wrt [s; u; s_next; u_next] by complex-step differentiation"""
+        eps = 1e-30
+        args = [s.astype(complex), u.astype(complex), sn.astype(complex), un.astype(complex)]
+        out = np.empty(s.shape[:-1] + (self.nk, 2 * self.f))
+        col = 0
+        for a, w in enumerate((self.nx, self.nu, self.nx, self.nu)):
+            for c in range(w):
+                pert = [v.copy() if i == a else v for i, v in enumerate(args)]
+                pert[a][..., c] += 1j * eps
+                out[..., :, col] = np.asarray(self.kfun(*pert)).imag / eps
+                col += 1
+        return out
+
+    def link_values(self, x):
+        s, u = self.frames(x)
+        return np.asarray(self.kfun(s[:, :-1], u[:, :-1], s[:, 1:], u[:, 1:])).reshape(x.shape[0], -1)
 
     def path_bounds(self):
         """([N, nh], [N, nh]) bounds of the path constraint per frame"""
@@ -176,7 +207,7 @@ class StageOCP:
         self.nvar = self.N * self.f
         self.n = self.np + self.nvar
         self.ngd = (self.N - 1) * self.nx                 # dynamics rows
-        self.ng = self.ngd + self.N * self.nh             # all general rows: dynamics, then nh path rows per frame
+        self.ng = self.ngd + self.N * self.nh + (self.N - 1) * self.nk    # all general rows: dynamics, nh path rows per frame, nk link rows per stage
         self.m = self.n + self.ng
         self.general_cost = self.lcost is not None
         if self.general_cost:
@@ -218,8 +249,11 @@ class StageOCP:
         self._A_id = np.zeros(n, np.int64)
         self._A_next = np.zeros((N, nx), np.int64)          # slot of +1 in row g_{k-1}[i], col s_k[i] (k>=1)
         self._A_blk = np.zeros((N - 1, nx, f), np.int64)    # slot of -dF[r, c] for stage k
-        nh = self.nh
+        nh = self.nh; nk = self.nk
         self._A_h = np.zeros((N, nh, f), np.int64)          # slot of +dh[r, c] for frame k
+        self._A_k0 = np.zeros((max(N - 1, 0), nk, f), np.int64)   # slot of d r_k / d frame_k [r, c]
+        self._A_k1 = np.zeros((max(N - 1, 0), nk, f), np.int64)   # slot of d r_k / d frame_{k+1} [r, c]
+        krow0 = n + (N - 1) * nx + N * nh
         for j in range(npp):
             self._A_id[j] = len(Ai); Ai.append(j); Ap.append(len(Ai))
         for k in range(N):
@@ -233,6 +267,12 @@ class StageOCP:
                         self._A_blk[k, r, c] = len(Ai); Ai.append(n + k * nx + r)
                 for r in range(nh):
                     self._A_h[k, r, c] = len(Ai); Ai.append(n + (N - 1) * nx + k * nh + r)
+                if k >= 1:
+                    for r in range(nk):
+                        self._A_k1[k - 1, r, c] = len(Ai); Ai.append(krow0 + (k - 1) * nk + r)
+                if k < N - 1:
+                    for r in range(nk):
+                        self._A_k0[k, r, c] = len(Ai); Ai.append(krow0 + k * nk + r)
                 Ap.append(len(Ai))
         self.Ap = np.asarray(Ap, np.int32); self.Ai = np.asarray(Ai, np.int32)
 
@@ -381,6 +421,11 @@ class StageOCP:
         if self.nh:
             A[:, self._A_h.ravel()] = self.dh(s, u).reshape(B, -1)
             g = np.concatenate([g, np.asarray(self.hfun(s, u)).reshape(B, -1)], axis=1)
+        if self.nk:
+            Jk = self.dk(s[:, :-1], u[:, :-1], s[:, 1:], u[:, 1:])          # [B, N-1, nk, 2 f]
+            A[:, self._A_k0.ravel()] = Jk[..., :f].reshape(B, -1)
+            A[:, self._A_k1.ravel()] = Jk[..., f:].reshape(B, -1)
+            g = np.concatenate([g, self.link_values(x)], axis=1)
         c = np.concatenate([p, x, g], axis=1)
         l = np.concatenate([p, lbx, lbg], axis=1) - c
         uu = np.concatenate([p, ubx, ubg], axis=1) - c
@@ -399,7 +444,10 @@ class StageOCP:
         lbg = np.zeros((B, self.ng)); ubg = np.zeros((B, self.ng))
         if self.nh:
             lo, hi = self.path_bounds()
-            lbg[:, self.ngd:] = lo.ravel(); ubg[:, self.ngd:] = hi.ravel()
+            lbg[:, self.ngd:self.ngd + self.N * self.nh] = lo.ravel(); ubg[:, self.ngd:self.ngd + self.N * self.nh] = hi.ravel()
+        if self.nk:
+            lo, hi = self.link_bounds()
+            lbg[:, self.ngd + self.N * self.nh:] = lo.ravel(); ubg[:, self.ngd + self.N * self.nh:] = hi.ravel()
         return lbx, ubx, lbg, ubg
 
 

@@ -62,6 +62,16 @@ class Path(Expr):
         self.h, self.state, self.inp, self.size = h, state, inp, int(size)
 
 
+class Link(Expr):
+    """k(state_k, input_k, state_{k+1}, input_{k+1}) of two consecutive frames: a constraint expression that couples them beyond the
+    dynamics -- rate limits u_{k+1} - u_k, slew limits on a state -- given as a NumPy callable on [..., nx], [..., nu], [..., nx],
+    [..., nu] returning [..., size]; used with addInequalityConstraint(name, lower, Link(...), upper) on every stage k = 0 .. N-2.
+    Stands for the SX expressions over several frames the reference accepts (src/OptimalControlProblem.cpp:448-489)."""
+
+    def __init__(self, k, state, inp, state_next, inp_next, size):
+        self.k, self.state, self.inp, self.state_next, self.inp_next, self.size = k, state, inp, state_next, inp_next, int(size)
+
+
 class StageCost(Expr):
     """l(state, input, reference) of one frame: a general scalar cost term given as a NumPy callable on [..., nx], [..., nu],
     [..., nx] returning [...]; used with addScalarCost(StageCost(...)) on every frame (the last frame may use another function:
@@ -159,9 +169,10 @@ class OCPConfig:
 class _FacadeStageOCP(models.StageOCP):
     name = "facade_ocp"
 
-    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi, h=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None):
+    def __init__(self, nx, nu, N, dt, Q, R, F, lo, hi, h=None, nh=0, h_lo=None, h_hi=None, lcost=None, lterm=None, k=None, nk=0, k_lo=None, k_hi=None):
         self.nx, self.nu, self._F, self._lo, self._hi = nx, nu, F, lo, hi
         self._h, self.nh, self.h_lo, self.h_hi = h, int(nh), h_lo, h_hi
+        self._k, self.nk, self.k_lo, self.k_hi = k, int(nk), k_lo, k_hi
         self.lcost, self.lterm = lcost, lterm
         super().__init__(N, dt, Q, R)
 
@@ -170,6 +181,9 @@ class _FacadeStageOCP(models.StageOCP):
 
     def hfun(self, s, u):
         return self._h(s, u)
+
+    def kfun(self, s, u, sn, un):
+        return self._k(s, u, sn, un)
 
     def frame_bounds(self):
         return self._lo, self._hi
@@ -307,10 +321,11 @@ class OptimalControlProblem:
         N, f = cfg.getHorizon(), cfg.getFrameSize()
         dyn_idx = [i for i, c in enumerate(self.constraints_) if isinstance(c, Diff) and isinstance(c.b, Dynamics)]
         path_idx = [i for i, c in enumerate(self.constraints_) if isinstance(c, Path)]
-        dyn = [self.constraints_[i] for i in dyn_idx]; path = [self.constraints_[i] for i in path_idx]
-        if len(dyn) + len(path) != len(self.constraints_) or len(dyn) != N - 1 or len(path) not in (0, N):
-            raise NotImplementedError("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames and one "
-                                      "per-frame path constraint Path(h, state_k, input_k) on every frame")
+        link_idx = [i for i, c in enumerate(self.constraints_) if isinstance(c, Link)]
+        dyn = [self.constraints_[i] for i in dyn_idx]; path = [self.constraints_[i] for i in path_idx]; link = [self.constraints_[i] for i in link_idx]
+        if len(dyn) + len(path) + len(link) != len(self.constraints_) or len(dyn) != N - 1 or len(path) not in (0, N) or len(link) not in (0, N - 1):
+            raise NotImplementedError("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames, one per-frame path "
+                                      "constraint Path(h, state_k, input_k) on every frame and one link constraint Link(k, frame_k, frame_{k+1}) on every stage")
         s0, u0, F = dyn[0].b.state, dyn[0].b.inp, dyn[0].b.F
         nx, nu = s0.size, u0.size
         if s0.offset != 0 or u0.offset != nx or nx + nu != f:
@@ -361,9 +376,20 @@ class OptimalControlProblem:
             h_lo = np.stack([self.constraintLowerBounds_[i] for i in path_idx]); h_hi = np.stack([self.constraintUpperBounds_[i] for i in path_idx])
             if (h_lo == h_lo[0]).all() and (h_hi == h_hi[0]).all():
                 h_lo, h_hi = h_lo[0], h_hi[0]
-        # rows of the compiled model: dynamics rows in frame order, then the path rows in frame order
-        self._row_order = [i for _, i in sorted((self.constraints_[i].a.step, i) for i in dyn_idx)] + path_idx
-        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi, lcost, lterm)
+        kf = None; nk = 0; k_lo = k_hi = None
+        if link:
+            link_idx.sort(key=lambda i: self.constraints_[i].state.step); link = [self.constraints_[i] for i in link_idx]
+            kf, nk = link[0].k, link[0].size
+            for k, c in enumerate(link):
+                if not (c.k == kf and c.size == nk and c.state.step == k and c.inp.step == k and c.state_next.step == k + 1 and c.inp_next.step == k + 1
+                        and c.state.name == s0.name and c.inp.name == u0.name and c.state_next.name == s0.name and c.inp_next.name == u0.name):
+                    raise NotImplementedError("the link constraint must be the same function of (frame k, frame k + 1) on every stage")
+            k_lo = self.constraintLowerBounds_[link_idx[0]]; k_hi = self.constraintUpperBounds_[link_idx[0]]
+            if any((self.constraintLowerBounds_[i] != k_lo).any() or (self.constraintUpperBounds_[i] != k_hi).any() for i in link_idx):
+                raise NotImplementedError("the link constraint's bounds must be the same on every stage")
+        # rows of the compiled model: dynamics rows in frame order, then the path rows in frame order, then the link rows in stage order
+        self._row_order = [i for _, i in sorted((self.constraints_[i].a.step, i) for i in dyn_idx)] + path_idx + link_idx
+        return _FacadeStageOCP(nx, nu, N, cfg.getDt(), Q, R, F, cfg.getLowerBounds()[0], cfg.getUpperBounds()[0], h, nh, h_lo, h_hi, lcost, lterm, kf, nk, k_lo, k_hi)
 
     # -- computeOptimalTrajectory (:78-222), CUDA_SQP arm
     def computeOptimalTrajectory(self, frame, reference):

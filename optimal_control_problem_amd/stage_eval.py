@@ -74,9 +74,10 @@ class StageEvaluator:
                 if isinstance(model, cls) and model.name == cls.name and type(model).F is cls.F and type(model).cdyn is cls.cdyn:
                     zoo = True
             general = bool(getattr(model, "general_cost", False))
-            use_codegen = (not zoo or model.nh > 0 or general) if codegen is None else bool(codegen)
-            if not use_codegen and (model.nh > 0 or not zoo or general):
-                raise ValueError("this model needs the generated evaluator (codegen=True): it is not a built-in zoo model, or has a path "
+            nk = int(getattr(model, "nk", 0))
+            use_codegen = (not zoo or model.nh > 0 or nk > 0 or general) if codegen is None else bool(codegen)
+            if not use_codegen and (model.nh > 0 or nk > 0 or not zoo or general):
+                raise ValueError("this model needs the generated evaluator (codegen=True): it is not a built-in zoo model, or has a path / link "
                                  "constraint or a general stage cost")
             _lib.check(L.mpcqp_stage_default(MODEL_IDS.get(model.name, 0) if zoo else 0, int(model.N), C.byref(d)))
             d.dt = float(model.dt)
@@ -90,7 +91,8 @@ class StageEvaluator:
                 from . import codegen as cg
                 h_lo, h_hi = model.path_bounds()
                 self.tape = cg.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, h_lo[0] if model.nh else None, h_hi[0] if model.nh else None,
-                                     lcost=model.lcost if general else None, lterm=model.lterm if general else None)
+                                     lcost=model.lcost if general else None, lterm=model.lterm if general else None,
+                                     kfun=model.kfun if nk else None, nk=nk, k_lo=model.k_lo if nk else None, k_hi=model.k_hi if nk else None)
                 self.library = cg.build_device_library(self.tape)
             else:
                 for i, v in enumerate(model_params(model)): d.par[i] = float(v)

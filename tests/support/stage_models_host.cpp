@@ -32,7 +32,7 @@ int sm_host_pattern(int model, int N, int *nnzP, int *nnzA, int *Pp, int *Pi, in
   int nx, nu; sm_model_dims(model, &nx, &nu);
   if (!nx) return 1;
   std::vector<int> a, b, c, d;
-  sm_build_pattern(nx, nu, N, 0, a, b, c, d);
+  sm_build_pattern(nx, nu, N, 0, 0, a, b, c, d);
   *nnzP = (int)b.size(); *nnzA = (int)d.size();
   if (Pp) { std::copy(a.begin(), a.end(), Pp); std::copy(b.begin(), b.end(), Pi); std::copy(c.begin(), c.end(), Ap); std::copy(d.begin(), d.end(), Ai); }
   return 0;

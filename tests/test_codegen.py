@@ -137,3 +137,46 @@ def test_path_constraint_host_formulation_and_generated_functor(built):
     src = codegen.emit_functor(tape)
     assert "nh = 2" in src and "-INFINITY" in src
     assert os.path.exists(codegen.build_device_library(tape))
+
+
+class CartPoleRate(models.CartPole):
+    """cart-pole with a link constraint between consecutive frames: a rate limit on the force and a (nonlinear) slew limit on the
+    pole tip -- the kind of term the reference accepts as any SX over the decision vector (src/OptimalControlProblem.cpp:448-489)"""
+    name = "cartpole_rate"; nk = 2; k_lo = [-4.0, -0.3]; k_hi = [4.0, 0.3]
+
+    def kfun(self, s, u, sn, un):
+        tip = lambda a: a[..., 0] + self.length * np.sin(a[..., 1])
+        return np.stack([un[..., 0] - u[..., 0], tip(sn) - tip(s)], axis=-1)
+
+
+def test_link_constraint_host_formulation_and_generated_functor(built):
+    """rows [p; x; g; h; r]: A's r rows are dK/d(frame_k, frame_{k+1}) (checked against central differences), l / u are the bounds
+    shifted by K(x); the traced + generated K functor (g++ build) reproduces kfun and its complex-step Jacobian"""
+    mdl = CartPoleRate(8, 0.02)
+    assert (mdl.ngd, mdl.ng, mdl.m) == (7 * 4, 7 * 4 + 7 * 2, mdl.n + 7 * 4 + 7 * 2)
+    rng = np.random.default_rng(0); B = 2
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = rng.normal(0, 0.1, (B, 4))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    _, A = ls.dense(0)
+    rows = lambda xv: np.concatenate([mdl.constraints(xv[None])[0], mdl.link_values(xv[None])[0]])
+    J = np.zeros((mdl.ng, mdl.nvar))
+    for j in range(mdl.nvar):
+        d = np.zeros(mdl.nvar); d[j] = 1e-6
+        J[:, j] = (rows(x[0] + d) - rows(x[0] - d)) / 2e-6
+    assert np.abs(A[mdl.n:, mdl.np:] - J).max() < 1e-8
+    kv = mdl.link_values(x)
+    assert np.array_equal(ls.u[:, mdl.n + mdl.ngd:], np.tile(mdl.k_hi, mdl.N - 1) - kv) and np.array_equal(ls.l[:, mdl.n + mdl.ngd:], np.tile(mdl.k_lo, mdl.N - 1) - kv)
+    for j in range(ls.n):
+        assert (np.diff(ls.Ai[ls.Ap[j]:ls.Ap[j + 1]]) > 0).all()
+    tape = codegen.trace(mdl.F, mdl.nx, mdl.nu, kfun=mdl.kfun, nk=mdl.nk, k_lo=mdl.k_lo, k_hi=mdl.k_hi)
+    L = C.CDLL(codegen.build_host_library(tape)); L.user_host_link.argtypes = [C.c_void_p] * 6
+    assert L.user_host_nk() == 2 and L.user_host_nh() == 0
+    s, u, sn, un = x[0, :4].copy(), x[0, 4:5].copy(), x[0, 5:9].copy(), x[0, 9:10].copy()
+    out = np.zeros(2); jac = np.zeros((2, 10))
+    L.user_host_link(s.ctypes.data, u.ctypes.data, sn.ctypes.data, un.ctypes.data, out.ctypes.data, jac.ctypes.data)
+    assert np.abs(out - mdl.kfun(s, u, sn, un)).max() < 1e-15
+    assert np.abs(jac - mdl.dk(s[None], u[None], sn[None], un[None])[0]).max() < 1e-13
+    src = codegen.emit_functor(tape)
+    assert "nk = 2" in src and "sn[" in src and "un[" in src
+    assert os.path.exists(codegen.build_device_library(tape))

@@ -332,6 +332,98 @@ def test_facade_path_constraint(built):
     assert (np.abs(X[:, 1:, 2] * X[:, 1:, 3]) <= 0.4 + 5e-2).all()
 
 
+def test_link_constraints_on_device(built):
+    """constraints that couple consecutive frames beyond the dynamics (rate limit u_{k+1} - u_k, slew limit of the pole tip):
+    rows [p; x; g; h; r] through the generated evaluator equal the host formulation, the QP honours them, the device SQP loop equals
+    the host loop, and the rate limit is active in the result"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver, SQPOptimizationSolver
+    from optimal_control_problem_amd.stage_eval import StageEvaluator
+    from tests.test_codegen import CartPoleRate
+    B, N = 20, 12
+    mdl = CartPoleRate(N, 0.02)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = np.zeros((B, 4))
+    frame0 = x[:, :mdl.f].copy()
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(frame0)
+    ref = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    ev = StageEvaluator(mdl)
+    assert ev.library is not None and (ev.m, ev.ng) == (mdl.m, mdl.ng) and (ev.Ai == mdl.Ai).all() and (ev.Ap == mdl.Ap).all()
+    out = ev.eval(_dev(p), _dev(x), _dev(lbx), _dev(ubx), _dev(lbg), _dev(ubg))
+    for k, r in (("P", ref.P), ("q", ref.q), ("A", ref.A), ("l", ref.l), ("u", ref.u)):
+        assert _close(out[k].cpu().numpy(), r, 1e-12), k
+    f, g = ev.merit(_dev(p), _dev(x))
+    kv = mdl.link_values(x).reshape(B, N - 1, 2)
+    viol = np.maximum(np.maximum(np.asarray(mdl.k_lo) - kv, kv - np.asarray(mdl.k_hi)).max(axis=(1, 2)), np.abs(mdl.constraints(x)).max(axis=1))
+    assert _close(g.cpu().numpy(), viol, 1e-11)
+    qp = BatchQP(ev.n, ev.m, B, ev.Pp, ev.Pi, ev.Ap, ev.Ai)
+    qp.update(out["P"], out["q"], out["A"], out["l"], out["u"]); qp.solve(); got = qp.get(); qp.close()
+    assert (got["status"] == 1).all()
+    z = got["z"][:, mdl.n + mdl.ngd:]                       # A dx on the link rows stays inside the shifted bounds (ADMM tolerance)
+    assert (z <= ref.u[:, mdl.n + mdl.ngd:] + 1e-2).all() and (z >= ref.l[:, mdl.n + mdl.ngd:] - 1e-2).all()
+    ev.close()
+    arg = dict(lbx=lbx, ubx=ubx, lbg=lbg, ubg=ubg, p=p)
+    opt = {"max_iter": 6, "alpha": 0.7}
+    host = SQPOptimizationSolver(mdl, opt, batch=B); dev = DeviceSQPOptimizationSolver(mdl, opt, batch=B)
+    host.setInitialGuess(x); dev.setInitialGuess(x)
+    rh = host.getOptimalSolution(arg); rd = dev.getOptimalSolution(arg)
+    assert np.abs(rd["x"] - rh["x"]).max() <= 1e-6 * (1 + np.abs(rh["x"]).max())
+    du = np.diff(rd["x"].reshape(B, N, mdl.f)[:, :, 4], axis=1)
+    assert (np.abs(du) <= 4.0 + 0.3).all()
+    free = models.CartPole(N, 0.02)                          # the same problem without the limits moves the force faster: the limit binds
+    hf = SQPOptimizationSolver(free, opt, batch=B); hf.setInitialGuess(x)
+    fl = free.stacked_bounds(frame0)
+    rf = hf.getOptimalSolution(dict(lbx=fl[0], ubx=fl[1], lbg=fl[2], ubg=fl[3], p=p))
+    assert np.abs(np.diff(rf["x"].reshape(B, N, mdl.f)[:, :, 4], axis=1)).max() > np.abs(du).max() + 0.5
+    host.qpSolver_.close(); hf.qpSolver_.close(); dev.close()
+
+
+def test_facade_rate_limit(built):
+    """OptimalControlProblem.addInequalityConstraint with a Link(...) expression on every stage (a rate limit on the input):
+    host loop = device-resident loop (gen_code), and the limit holds"""
+    import yaml
+    from optimal_control_problem_amd.ocp import Dynamics, Link, OptimalControlProblem
+    text = """
+      discretization_settings: {dt: 0.05, horizon: 12}
+      solver_settings: {verbose: false, gen_code: %s, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 1.0, step_num: 3}}
+      OCP_variables:
+        - {name: state, size: 2, lower_bound: [-.inf, -2.0], upper_bound: [.inf, 2.0]}
+        - {name: input, size: 1, lower_bound: [-1.0], upper_bound: [1.0]}
+    """
+    def step(s, u):
+        h = 0.05
+        return np.stack([s[..., 0] + h * s[..., 1] + 0.5 * h * h * u[..., 0], s[..., 1] + h * u[..., 0]], axis=-1)
+
+    def rate(s, u, sn, un):
+        return np.stack([un[..., 0] - u[..., 0]], axis=-1)
+
+    class DI(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_
+            ref = self.setReference(2)
+            for k in range(cfg.getHorizon()):
+                self.addVectorCost([10.0, 1.0], cfg.getVariable(k, "state") - ref)
+                self.addVectorCost([0.1], cfg.getVariable(k, "input"))
+                if k < cfg.getHorizon() - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(step, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")))
+                    self.addInequalityConstraint("rate", [-0.15], Link(rate, cfg.getVariable(k, "state"), cfg.getVariable(k, "input"),
+                                                                      cfg.getVariable(k + 1, "state"), cfg.getVariable(k + 1, "input"), 1), [0.15])
+
+    B = 6
+    rng = np.random.default_rng(4)
+    frame = np.concatenate([rng.uniform(-2, 2, (B, 1)), rng.uniform(-1, 1, (B, 1)), np.zeros((B, 1))], axis=1); ref = np.zeros((B, 2))
+    res = {}
+    for flag in ("false", "true"):
+        ocp = DI(yaml.safe_load(text % flag), batch=B)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert (ocp.model_.nk, ocp.model_.ng) == (1, 11 * 2 + 11)
+        res[flag] = ocp.computeOptimalTrajectory(frame, ref)
+    assert np.abs(res["true"] - res["false"]).max() <= 1e-6 * (1 + np.abs(res["false"]).max())
+    U = res["true"].reshape(B, 12, 3)[:, :, 2]
+    assert (np.abs(np.diff(U, axis=1)) <= 0.15 + 2e-2).all() and np.abs(np.diff(U, axis=1)).max() > 0.1      # the limit holds and binds
+
+
 def test_per_frame_weights_on_device(built):
     """mpcqp_stage_set_weights (terminal cost / weight ramps): device evaluation and merit equal the host formulation, for a
     built-in functor and for generated dynamics; the facade compiles per-step addVectorCost weights into them"""
