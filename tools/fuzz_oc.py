@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle sweep of the on-chip mode (MPCQP_VARIANT=oc4) over stage-OCP patterns: random state / input sizes, horizons,
+weights, nonlinear dynamics and iterates -- block tridiagonal + arrow patterns with single and twisted chains, phantom slots, hubs that
+share their block with the last frame.  Sizes the instance does not take (ERR_LIMIT) are counted and skipped.  Each case: a cold solve
+and a kept-workspace solve (new q, shifted bounds), against the oracle's.  usage: python tools/fuzz_oc.py [n_cases] [seed0]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MPCQP_VARIANT"] = "oc4"
+import numpy as np
+
+from optimal_control_problem_amd import _lib, models
+from optimal_control_problem_amd.batch_qp import BatchQP
+from oracle import oracle as orc
+
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tight = soft = bad = skipped = 0
+for c in range(ncase):
+    rng = np.random.default_rng(5000 + seed0 + c)
+    nx = int(rng.integers(2, 13)); nu = int(rng.integers(1, 5)); N = int(rng.integers(4, 26)); B = int(rng.integers(1, 6))
+    Am = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx)); Bm = 0.3 * rng.normal(size=(nx, nu)); w = rng.normal(size=nx)
+
+    class M(models.StageOCP):
+        name = "fuzz"
+        def F(self, s, u):
+            return s @ Am.T + u @ Bm.T + 0.05 * np.sin(s * w)
+        def frame_bounds(self):
+            return np.concatenate([np.full(nx, -5.0), np.full(nu, -1.0)]), np.concatenate([np.full(nx, 5.0), np.full(nu, 1.0)])
+    M.nx, M.nu = nx, nu
+    mdl = M(N, 0.05, rng.uniform(0.1, 10.0, nx), rng.uniform(0.01, 1.0, nu))
+    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = rng.normal(0, 0.2, (B, nx))
+    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
+    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
+    dims = "nx=%d nu=%d N=%d B=%d n=%d m=%d" % (nx, nu, N, B, ls.n, ls.m)
+    try:
+        qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    except _lib.MpcqpError as e:
+        if e.code == _lib.ERR_LIMIT:
+            skipped += 1; continue
+        raise
+    assert qp.plan_info()["variant"] == 204
+    qp.keep_workspace(True)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
+    q2 = ls.q * 1.2 + 0.05 * rng.normal(size=ls.q.shape); sh = 0.02 * rng.normal(size=ls.l.shape)
+    for tag, run_g, run_o in (("cold", lambda: (qp.update(ls.P, ls.q, ls.A, ls.l, ls.u), qp.solve(), qp.get())[2], lambda: st.solve(ls.P, ls.q, ls.A, ls.l, ls.u)),
+                              ("kept", lambda: (qp.update_vectors(q2, ls.l + sh, ls.u + sh), qp.solve(), qp.get())[2], lambda: st.solve_vectors(q2, ls.l + sh, ls.u + sh))):
+        got, ref = run_g(), run_o()
+        fin = np.isfinite(ref["x"])
+        err = np.abs(got["x"][fin] - ref["x"][fin]).max() / (1 + np.abs(ref["x"][fin]).max()) if fin.any() else 0.0
+        same = (got["status"] == ref["status"]).all() and np.array_equal(np.isfinite(got["x"]), fin)
+        if same and (got["iters"] == ref["iters"]).all() and err <= 1e-6:
+            tight += 1
+        elif same and err <= 2e-2 and ref["iters"].max() >= 200:
+            soft += 1; print("tolerance-level %s case %d %s iters %s/%s rel err %.2e" % (tag, c, dims, got["iters"], ref["iters"], err))
+        else:
+            bad += 1; print("MISMATCH %s case %d %s status %s/%s iters %s/%s rel err %.2e" % (tag, c, dims, got["status"], ref["status"], got["iters"], ref["iters"], err))
+    qp.close()
+print("done: %d cases (%d skipped: outside the instance's limits), %d solves at the tight bar, %d tolerance-level, %d mismatches" % (ncase, skipped, tight, soft, bad))
+sys.exit(1 if bad else 0)
