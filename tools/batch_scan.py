@@ -1,0 +1,20 @@
+import os, sys, json, subprocess
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from optimal_control_problem_amd import models
+from optimal_control_problem_amd.batch_qp import BatchQP
+def run(B, env):
+    for k in ("MPCQP_VARIANT","MPCQP_LDS_MIN","MPCQP_NO_OC"): os.environ.pop(k, None)
+    os.environ.update(env)
+    mdl, ls, _ = models.make_workload("quadrotor", B, N=20)
+    d = [torch.as_tensor(a, device="cuda") for a in (ls.P, ls.q, ls.A, ls.l, ls.u)]
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai); qp.set_dispatch_hint(False)
+    ms=[]
+    for _ in range(5):
+        qp.update(*d); qp.solve(); qp.get(); ms.append(qp.last_kernel_ms())
+    v = qp.plan_info()["variant"]; qp.close()
+    return v, min(ms[1:])
+for env in ({}, {"MPCQP_NO_OC":"1"}, {"MPCQP_LDS_MIN":"90000"}):
+    for B in (512, 1024, 2048, 4096, 8192, 16384):
+        v, ms = run(B, env)
+        print(env, "B=%d variant %d: %.3f ms -> %.0f QP/s" % (B, v, ms, B/ms*1e3), flush=True)
