@@ -330,3 +330,191 @@ extern "C" int plan_check_layout(int n, int m, const int *Pp, const int *Pi, con
   }
   return 0;
 }
+
+// ---- on-chip mode (kernel_onchip.hpp): lane-accurate emulation of the solve -- the MFMA operand / result layouts (v_mfma_f64_16x16x4_f64:
+// A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15], D[m = (l >> 4) + 4 g][n = l & 15]), the index map phi, the swizzled LDS block image
+// read as rows and as columns, the chain tables, the per-wave position slots with phantoms, the junction term and the hub phases -- on the
+// factor the level-parallel plan produces, with a hazard check between the waves of every phase.
+// returns 0 ok, 1 plan error, 2 not positive definite, 3 hazard, 5 the pattern is not taken by the on-chip plan; info: nbc, has_hub, junc, nlds, nhr, lds bytes
+namespace {
+struct Wave { double v[64][4]; };   // one d4 per lane
+inline int phi(int m) { return 4 * (m & 3) + (m >> 2); }
+inline int swz(int r, int c) { return ((r ^ ((r >> 2) & 1)) << 4) | (c ^ (((r >> 1) & 3) << 2) ^ (((r >> 3) & 1) << 1)); }
+void mfma(const double a[64], const double b[64], Wave &acc) {
+  double A[16][4], B[4][16];
+  for (int l = 0; l < 64; l++) { A[l & 15][l >> 4] = a[l]; B[l >> 4][l & 15] = b[l]; }
+  for (int l = 0; l < 64; l++) for (int g = 0; g < 4; g++) {
+    const int m = (l >> 4) + 4 * g, n = l & 15;
+    double s = 0; for (int k = 0; k < 4; k++) s += A[m][k] * B[k][n];
+    acc.v[l][g] += s;
+  }
+}
+void mv(const Wave &a, const Wave &v, Wave &acc) {     // oc_mv: 4 MFMAs, register i of the block against register i of the vector
+  for (int i = 0; i < 4; i++) { double x[64], y[64]; for (int l = 0; l < 64; l++) { x[l] = a.v[l][i]; y[l] = v.v[l][i]; } mfma(x, y, acc); }
+}
+Wave ldF(const double *blk) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = blk[swz(r, 4 * kk + i)]; } return w; }
+Wave ldT(const double *blk) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = blk[swz(4 * kk + i, r)]; } return w; }
+Wave ldFg(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = sign * blk[r * BS + 4 * kk + i]; } return w; }
+Wave ldTg(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = sign * blk[(4 * kk + i) * BS + r]; } return w; }
+Wave ldB(const double *vec, int p) { Wave w; for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) w.v[l][i] = vec[BS * p + 4 * (l >> 4) + i]; return w; }
+bool stB(double *vec, int p, const Wave &w) {          // every lane of a group stores: they must agree
+  for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) {
+    if (w.v[l][i] != w.v[l & ~15][i]) return false;
+    vec[BS * p + 4 * (l >> 4) + i] = w.v[l][i];
+  }
+  return true;
+}
+Wave zero() { Wave w; std::memset(&w, 0, sizeof(w)); return w; }
+Wave add(Wave a, const Wave &b) { for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) a.v[l][i] += b.v[l][i]; return a; }
+}  // namespace
+
+extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH,
+                               const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  const int nw = 4;
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, true);
+  if (!pl.error.empty()) return 1;
+  ResPlan rp = build_res_plan(pl, nw, false);
+  OcPlan oc = build_oc_plan(pl, nw, 1 << 20, NG, NH);
+  if (info) { info[0] = oc.nbc; info[1] = oc.has_hub; info[2] = oc.junc; info[3] = oc.nlds; info[4] = oc.nhr; info[5] = oc.ok ? lds_bytes_oc(pl, rp, oc) : 0; }
+  if (!oc.ok) return 5;
+  // ---- factor (as plan_execute_res: assembly + level-parallel LDL')
+  std::vector<double> vA, vAt, vP;
+  ell_fill(pl.A, Aval, vA); ell_fill(pl.At, Aval, vAt); ell_fill(pl.P, Pval, vP);
+  std::vector<double> dvec(pl.npad, 1.0);
+  for (int c = 0; c < pl.At.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int t = c * WAVE + lane; if (t >= pl.npad) continue;
+    double a = 0;
+    for (int s = pl.At.chunk_off[c]; s < pl.At.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.At.flag[p]) a += rho[pl.At.idx[p]] * vAt[p] * vAt[p]; }
+    dvec[t] = pl.perm[t] >= 0 ? sigma + a : 1.0;
+  }
+  std::vector<double> T((size_t)std::max(pl.nT, 1) * BLK, 0.0);
+  for (int c = 0; c < pl.A.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    int i = c * WAVE + lane; if (i >= m) continue;
+    for (int s = pl.A.chunk_off[c]; s < pl.A.chunk_off[c + 1]; s++) { long p = (long)s * WAVE + lane; if (pl.tpos[p] >= 0) T[pl.tpos[p]] = vA[p] * std::sqrt(rho[i]); }
+  }
+  std::vector<double> S((size_t)pl.nblk * BLK, 0.0), tmp((size_t)std::max(rp.ntemp, 1) * BLK, 0.0);
+  for (int b = 0; b < pl.nblk; b++) {
+    double *C = &S[(size_t)b * BLK];
+    for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) gemm_abt(&T[(size_t)pl.asm_a[g] * BLK], &T[(size_t)pl.asm_b[g] * BLK], C, 1.0);
+    for (int g = 0; g < 4; g++) for (int lane = 0; lane < WAVE; lane++) {
+      int row = (lane >> 4) + 4 * g, col = lane & 15;
+      int pi = pl.asm_pidx[(size_t)b * BLK + g * WAVE + lane];
+      if (pi >= 0) C[row * BS + col] += vP[pi];
+      if (pl.blk_diag[b] >= 0 && row == col) C[row * BS + col] += dvec[pl.blk_diag[b] * BS + row];
+    }
+  }
+  std::vector<int> pend_slot, pend_tmp;
+  for (int lev = 0; lev < rp.nlev; lev++) {
+    for (int ci = rp.lv_ptr[lev]; ci < rp.lv_ptr[lev + 1]; ci++) if (!sweep_inverse(&S[(size_t)rp.lv_diag[ci] * BLK])) return 2;
+    for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
+    pend_slot.clear(); pend_tmp.clear();
+    const int w0 = rp.lw_ptr[lev], nwk = rp.lw_ptr[lev + 1] - w0;
+    std::vector<double> tnew((size_t)std::max(nwk, 1) * BLK, 0.0);
+    for (int a = 0; a < nwk; a++) gemm_abt(&S[(size_t)rp.lw_slot[w0 + a] * BLK], &S[(size_t)rp.lw_g[w0 + a] * BLK], &tnew[(size_t)a * BLK], 1.0);
+    for (int a = 0; a < nwk; a++) std::memcpy(&tmp[(size_t)a * BLK], &tnew[(size_t)a * BLK], BLK * sizeof(double));
+    for (int w = 0; w < nw; w++) for (int u = rp.lu_ptr[lev * nw + w]; u < rp.lu_ptr[lev * nw + w + 1]; u++)
+      gemm_abt(&tmp[(size_t)rp.lu_tmp[u] * BLK], &S[(size_t)rp.lu_b[u] * BLK], &S[(size_t)rp.lu_dst[u] * BLK], -1.0);
+    for (int a = 0; a < nwk; a++) { pend_slot.push_back(rp.lw_slot[w0 + a]); pend_tmp.push_back(a); }
+  }
+  for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
+  // ---- oc_load_factor: LDS images (negated off-diagonal blocks, swizzled) and per-wave register blocks
+  const int *tab = oc.tab.data();
+  std::vector<double> BL((size_t)oc.nlds * BLK, 0.0);
+  for (int j = 0; j < oc.nlds; j++) {
+    const int src = tab[oc.o_fill + 3 * j], slot = tab[oc.o_fill + 3 * j + 1], neg = tab[oc.o_fill + 3 * j + 2];
+    if (slot < 0 || slot >= oc.nlds || src < 0 || src >= pl.nblk) return 1;
+    for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) BL[(size_t)slot * BLK + swz(r, c)] = (neg ? -1.0 : 1.0) * S[(size_t)src * BLK + r * BS + c];
+  }
+  std::vector<std::vector<Wave>> G(nw, std::vector<Wave>(NG, zero())), HF(nw, std::vector<Wave>(std::max(NH, 1), zero())), HT = HF;
+  std::vector<std::vector<int>> vpos(nw, std::vector<int>(NG)), hslot = vpos, okp = vpos;
+  const int zero_blk = pl.npad / BS + 5;
+  for (int w = 0; w < nw; w++) for (int s = 0; s < NG; s++) {
+    const int p = w + nw * s, pe = p < oc.nbc ? p : oc.nbc - 1;
+    okp[w][s] = p < oc.nbc; vpos[w][s] = p < oc.nbc ? p : zero_blk;
+    const int hs = tab[oc.o_pos + 5 * pe + 4]; hslot[w][s] = hs >= 0 ? hs : 0;
+    if (p < oc.nbc) {
+      G[w][s] = ldFg(&S[(size_t)tab[oc.o_pos + 5 * p] * BLK], 1.0);
+      const int hsrc = tab[oc.o_pos + 5 * p + 2];
+      if (s < NH && hsrc >= 0) { HF[w][s] = ldFg(&S[(size_t)hsrc * BLK], -1.0); HT[w][s] = ldTg(&S[(size_t)hsrc * BLK], -1.0); }
+    }
+  }
+  // ---- oc_solve
+  std::vector<double> R((size_t)pl.npad + OC_REXT, 0.0);
+  for (int j = 0; j < n; j++) R[pl.pos[j]] = rhs[j];
+  double *EXT = &R[pl.npad];
+  const int LE = tab[0], LF = tab[1], H = oc.nbc, f = (oc.junc && LF > 0) ? tab[oc.o_chainF + 2 * (LF - 1)] : -1;
+  const bool HUB = NH > 0;
+  if (HUB != (oc.has_hub != 0)) return 5;
+  std::vector<int> wr(pl.nb + 6, -1), rd(pl.nb + 6, 0);      // hazard tracking per vector block within a phase
+  bool hazard = false;
+  auto touch = [&](int w, int blk, bool write) {
+    if (wr[blk] >= 0 && wr[blk] != w) hazard = true;
+    if (write) { if (rd[blk] & ~(1 << w)) hazard = true; wr[blk] = w; } else rd[blk] |= 1 << w;
+  };
+  auto barrier = [&]() { std::fill(wr.begin(), wr.end(), -1); std::fill(rd.begin(), rd.end(), 0); };
+  const int ext0 = pl.npad / BS;
+  // F1
+  for (int w = 0; w < 2; w++) {
+    const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
+    if (len == 0) continue;
+    int e = 0; touch(w, tab[cb], false);
+    Wave x = ldB(R.data(), tab[cb]);
+    for (int k = 0; k + 1 < len; k++) {
+      const int slot = tab[cb + 2 * k + 1], pn = tab[cb + 2 * (k + 1)];
+      touch(w, pn, false);
+      Wave c = ldB(R.data(), pn);
+      mv(ldF(&BL[(size_t)slot * BLK]), x, c);
+      touch(w, pn, true);
+      if (!stB(R.data(), pn, c)) return 1;
+      x = c; e = k + 1;
+    }
+    if (w == 0 && oc.junc) { Wave c = zero(); mv(ldF(&BL[(size_t)tab[cb + 2 * e + 1] * BLK]), x, c); touch(w, ext0, true); if (!stB(EXT, 0, c)) return 1; }
+  }
+  barrier();
+  if (f >= 0) { const int w = f & (nw - 1); touch(w, f, false); touch(w, ext0, false); Wave t = add(ldB(R.data(), f), ldB(EXT, 0)); touch(w, f, true); stB(R.data(), f, t); }
+  std::vector<Wave> xh(nw, zero());
+  if (HUB) {
+    for (int w = 0; w < nw; w++) {
+      Wave hacc = zero();
+      for (int s = 0; s < NG; s++) {
+        touch(w, vpos[w][s], false);
+        const Wave t = ldB(R.data(), vpos[w][s]);
+        if (s < NH) mv(HF[w][s], t, hacc); else mv(ldF(&BL[(size_t)hslot[w][s] * BLK]), t, hacc);
+      }
+      touch(w, ext0 + 1 + w, true); stB(EXT, 1 + w, hacc);
+    }
+    barrier();
+    for (int w = 0; w < nw; w++) {
+      touch(w, H, false);
+      Wave th = ldB(R.data(), H);
+      for (int v = 0; v < nw; v++) { touch(w, ext0 + 1 + v, false); th = add(th, ldB(EXT, 1 + v)); }
+      mv(ldF(&BL[(size_t)oc.ghub_slot * BLK]), th, xh[w]);
+    }
+  }
+  for (int w = 0; w < nw; w++) for (int s = 0; s < NG; s++) {
+    touch(w, vpos[w][s], false);
+    const Wave t = ldB(R.data(), vpos[w][s]);
+    Wave d = zero(); mv(G[w][s], t, d);
+    if (HUB) { if (s < NH) mv(HT[w][s], xh[w], d); else mv(ldT(&BL[(size_t)hslot[w][s] * BLK]), xh[w], d); }
+    if (okp[w][s]) { touch(w, vpos[w][s], true); stB(R.data(), vpos[w][s], d); }
+  }
+  barrier();
+  if (HUB) { touch(nw - 1, H, true); stB(R.data(), H, xh[nw - 1]); }
+  for (int w = 0; w < 2; w++) {
+    const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
+    if (len == 0) continue;
+    int k = len - 2; Wave x;
+    if (w == 0 && oc.junc) { touch(w, f, false); x = ldB(R.data(), f); k = len - 1; } else { touch(w, tab[cb + 2 * (len - 1)], false); x = ldB(R.data(), tab[cb + 2 * (len - 1)]); }
+    for (; k >= 0; k--) {
+      const int p = tab[cb + 2 * k], slot = tab[cb + 2 * k + 1];
+      touch(w, p, false);
+      Wave c = ldB(R.data(), p);
+      mv(ldT(&BL[(size_t)slot * BLK]), x, c);
+      touch(w, p, true); stB(R.data(), p, c);
+      x = c;
+    }
+  }
+  if (hazard) return 3;
+  for (int j = 0; j < n; j++) sol[j] = R[pl.pos[j]];
+  return 0;
+}

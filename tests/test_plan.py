@@ -153,3 +153,49 @@ def test_slab_layout_and_schedule_bounds(built, name, N):
             info = np.zeros(8, np.int64)
             for split in (0, 10000):
                 assert L.plan_check_segments(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), nw + 100 * (force + 1) + split, _p(info)) == 0
+
+
+def _run_oc(ls, NG=5, NH=3, b=0, seed=0):
+    """the on-chip plan (plan.hpp build_oc_plan) through the lane-accurate emulation of kernel_onchip.hpp's solve in plan_interp.cpp:
+    MFMA operand layouts, phi, swizzled LDS images read as rows and columns, chain tables, phantom slots, junction and hub phases"""
+    L = C.CDLL(SO)
+    rng = np.random.default_rng(seed)
+    n, m = ls.n, ls.m
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(8, np.int64)
+    Pv = np.ascontiguousarray(np.broadcast_to(ls.P, (ls.batch, len(ls.Pi)))[b]); Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[b])
+    rc = L.plan_execute_oc(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), NG, NH, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
+    if rc == 0:
+        ref = np.linalg.solve(M, rhs)
+        assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
+    return rc, dict(nbc=info[0], has_hub=info[1], junc=info[2], nlds=info[3], nhr=info[4], lds=info[5])
+
+
+@pytest.mark.parametrize("name,N,expect", [("quadrotor", 20, dict(nbc=20, has_hub=1, junc=1, nlds=28, nhr=3)),      # the north-star size: twisted chains + hub
+                                           ("quadrotor", 12, dict(nbc=12, has_hub=1, junc=1, nhr=3)),              # phantom slots (12 positions, 5 per wave)
+                                           ("cartpole", 30, dict(has_hub=1, junc=0)),                             # one chain, the hub shares the last block
+                                           ("double_integrator", 20, dict(has_hub=1, junc=0))])
+def test_onchip_plan_emulated(built, name, N, expect):
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    rc, info = _run_oc(ls, b=1)
+    assert rc == 0, (rc, info)
+    for k, v in expect.items():
+        assert info[k] == v, (k, info)
+    if name == "quadrotor" and N == 20:
+        assert info["lds"] <= 80 * 1024                   # two workgroups per CU
+
+
+def test_onchip_plan_without_hub_and_limits(built):
+    """the reduced form's pattern (no parameter block): two chains meeting in their last element, no hub phases; sizes past the
+    instance's limits are refused by the plan, not mis-executed"""
+    mdl, ls, _ = models.make_workload("quadrotor", 2, N=20)
+    red, *_ = problems.reduce_qp(ls, list(range(mdl.np)))
+    rc, info = _run_oc(red, NG=5, NH=0, b=1)
+    assert rc == 0 and (info["nbc"], info["has_hub"], info["junc"], info["nlds"]) == (20, 0, 1, 19)
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=30)          # 30 chain blocks: more than five positions per wave
+    assert _run_oc(ls)[0] == 5
+    assert _run_oc(problems.random_qp(40, 30, 3))[0] == 0            # three blocks: a dense pattern still is chain + hub
+    assert _run_oc(problems.random_qp(120, 60, 3))[0] == 5           # eight dense blocks are not block tridiagonal + arrow
