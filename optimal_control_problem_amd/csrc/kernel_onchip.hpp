@@ -25,7 +25,8 @@
 // =========================================================================================================
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
-  int o_chainE, o_chainF, o_pos, o_fill, ghub_slot;
+  int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
+  int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
 };
 
@@ -108,6 +109,176 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
     }
   }
   bsync<NW>();
+}
+
+// =========================================================================================================
+// The block LDL' of this topology, on the matrix cores and in registers.  The generic level loop of factorize_res works in the slab:
+// every level is a handful of dependent L2 round trips (plan indices, operand tiles, temp tiles) between three workgroup barriers, and
+// the 16 pivots of an in-LDS sweep cost ~900 cycles each.  Here the two chain waves (0: chain E, 1: chain F) carry the diagonal
+// block from step to step in the MFMA C/D layout, and waves 2 / 3 follow one step behind with the hub row of "their" chain:
+//   chain wave, step J:  G_J = S_JJ^-1 (oc_sweep);  W' = G_J L';  S_next,next -= W L'        (L = S_next,J: the block below the diagonal)
+//   helper,  one behind: W_h' = G_J H_J';  S_hh -= W_h H_J';  H_next' = S_h,next' - L W_h'    (H_J = S_hub,J as updated so far)
+// With the layouts  D(X): lane 16 kk + n holds X[kk + 4 g][n]  and  A(X) = D(X'): X[n][kk + 4 g],  oc_mm(a, b) = D(Xa Xb) for a = A(Xa),
+// b = D(Xb), so every product above takes its operands from registers as the previous product (or a strided load from the slab)
+// left them.  Hand-overs go through LDS scratch blocks: G_J to the helper (double-buffered by step parity), chain E's term for the
+// junction block to chain F, the helpers' sums for the hub's diagonal block to wave 0, which inverts it last.
+// Results land in the slab exactly where factorize_res leaves them (G_J in the diagonal slots, W in the off-diagonal ones).
+// =========================================================================================================
+__device__ __forceinline__ d4 oc_ldD(const double *blk, const int lane) { const int o = (lane >> 4) * BS + (lane & 15); return d4{blk[o], blk[o + 4 * BS], blk[o + 8 * BS], blk[o + 12 * BS]}; }
+__device__ __forceinline__ void oc_stD(double *blk, const int lane, const d4 v) { const int o = (lane >> 4) * BS + (lane & 15); blk[o] = v[0]; blk[o + 4 * BS] = v[1]; blk[o + 8 * BS] = v[2]; blk[o + 12 * BS] = v[3]; }
+__device__ __forceinline__ d4 oc_ldA(const double *blk, const int lane) { const int o = (lane & 15) * BS + (lane >> 4); return d4{blk[o], blk[o + 4], blk[o + 8], blk[o + 12]}; }
+__device__ __forceinline__ void oc_stA(double *blk, const int lane, const d4 v) { const int o = (lane & 15) * BS + (lane >> 4); blk[o] = v[0]; blk[o + 4] = v[1]; blk[o + 8] = v[2]; blk[o + 12] = v[3]; }
+__device__ __forceinline__ d4 oc_ldS(const double *scr, const int lane) { return reinterpret_cast<const d4 *>(scr)[lane]; }       // LDS scratch block: a wave's four registers as they are
+__device__ __forceinline__ void oc_stS(double *scr, const int lane, const d4 v) { reinterpret_cast<d4 *>(scr)[lane] = v; }
+__device__ __forceinline__ d4 oc_mm(const d4 a, const d4 b, d4 acc) { return oc_mv(a, b, acc); }
+__device__ __forceinline__ double oc_readlane(const double v, const int l) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_readlane(a.i[0], l); r.i[1] = __builtin_amdgcn_readlane(a.i[1], l);
+  return r.d;
+}
+// 1 / d for a positive, normal d: v_rcp_f64 and two Newton steps (a full division adds scaling and a fix-up that the pivots of
+// an equilibrated KKT matrix do not need; the sweep is a chain of 16 of these)
+__device__ __forceinline__ double oc_rcp(const double d) {
+  double p = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, p, 1.0); p = __builtin_fma(p, e, p);
+  e = __builtin_fma(-d, p, 1.0); p = __builtin_fma(p, e, p);
+  return p;
+}
+// In-register inverse of an SPD block held in the D layout, by symmetric sweeps: sweeping pivot k (row u, pivot d = u_k) is the
+// rank-1 update  a <- a0 - (1/d) w w'  with w = u except w_k = -1, a0 = a with row and column k cleared -- one MFMA whose only
+// non-zero K slot is k & 3, which is also where the D layout keeps row k (register k >> 2 of lane group k & 3), for both operands:
+// a is symmetric.  Pivots > 0 <=> positive definite (they are the Cholesky pivots squared).  After 16 sweeps a = -inverse.
+__device__ __forceinline__ bool oc_sweep(d4 &a, const int lane) {
+  const int n = lane & 15, kk = lane >> 4;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < BS; k++) {
+    const int g = k >> 2, ks = k & 3;
+    const double row = a[g];
+    const double d = oc_readlane(row, 16 * ks + k);
+    ok = ok && d > 0.0;
+    const double p = oc_rcp(d);
+    const bool grp = kk == ks, colk = n == k;
+    const double w = grp ? (colk ? -1.0 : row) : 0.0;
+    const double bw = -p * w;
+    a[g] = grp ? 0.0 : a[g];
+#pragma unroll
+    for (int gg = 0; gg < 4; gg++) a[gg] = colk ? 0.0 : a[gg];
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(w, bw, a, 0, 0, 0);
+  }
+  a = -a;
+  return ok;
+}
+
+constexpr int OC_LDL_SCR = 8;     // LDS scratch blocks of oc_ldl (the stage region is at least this large: plan.hpp oc_stage_doubles)
+template <int NW, bool HUB>
+__device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double *slab, double *scr, double *red, const int wid, const int lane,
+                                       unsigned long long *t_sweep = nullptr) {
+  static_assert(NW == 4, "two chain waves and their two helpers");
+  // scratch blocks: 0..3 G hand-over [chain][step parity], 4 chain E's term for the junction's diagonal block, 5 for its hub block, 6..7 the helpers' sums
+  const int LE = oc_tab(ctab, 0), LF = oc_tab(ctab, 1);
+  const bool junc = oc.junc && LF > 0;
+  const int S = junc ? max(LE + 1, LF) : LE;          // chain steps run in phases 0 .. S - 1 (chain F keeps its last step, the junction, for phase S - 1); helpers one phase behind
+  const int ch = wid & 1;
+  const bool helper = wid >= 2;
+  const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
+  const int *pt = oc.tab + oc.o_pos;
+  // block ids of the chain's steps, step i in lane i (read back with v_readlane: no memory latency inside a phase)
+  const int pv = L > 0 ? ctab[cb + 2 * min(lane, L - 1)] : 0;
+  const int gsv = pt[5 * pv], csv = pt[5 * pv + 1], hsv = pt[5 * pv + 2];
+  // the chain step worked on in phase s: chain E step s; chain F step s, its last one held back until chain E has finished
+  auto step_of = [&](const int s) -> int {
+    if (s < 0) return -1;
+    if (ch == 0) return s < LE ? s : -1;
+    if (s < LF - 1) return s;
+    return (s == S - 1 && LF > 0) ? LF - 1 : -1;
+  };
+  bool ok = true;
+  d4 Dc = {0, 0, 0, 0}, Wp = {0, 0, 0, 0}, Hr = {0, 0, 0, 0}, Lc = {0, 0, 0, 0}, Ln = {0, 0, 0, 0}, Sn = {0, 0, 0, 0}, Hc = {0, 0, 0, 0}, Hn = {0, 0, 0, 0}, Sh = {0, 0, 0, 0};
+  int pend = -1;
+  // Slab operands are fetched a whole step ahead (a slab read is an L2 / fabric round trip of a few thousand cycles).  What a fetch may
+  // read early: L_k and the diagonal block below it are first written by this chain wave at step k (W over L: one phase after, see
+  // below), S_hub,next by this helper at its step for `next`.
+  auto chain_fetch = [&](const int k) {            // operands of chain step k: L_k = S_next,k and S_next,next
+    const bool last = k == L - 1, tojunc = ch == 0 && last && junc;
+    if (!last || tojunc) Ln = oc_ldA(slab + (long)__builtin_amdgcn_readlane(csv, k) * BLK, lane);
+    if (!last) Sn = oc_ldD(slab + (long)__builtin_amdgcn_readlane(gsv, k + 1) * BLK, lane);
+  };
+  if (L > 0) {
+    if (!helper) { Dc = oc_ldD(slab + (long)__builtin_amdgcn_readlane(gsv, 0) * BLK, lane); chain_fetch(0); }
+    else if (HUB) Hr = oc_ldA(slab + (long)__builtin_amdgcn_readlane(hsv, 0) * BLK, lane);
+  }
+  const int nph = HUB ? S + 1 : S;
+  for (int s = 0; s < nph; s++) {
+    if (!helper) {
+      if (pend >= 0) { oc_stA(slab + (long)pend * BLK, lane, Wp); pend = -1; }     // one phase late: the helper has read L by now
+      const int k = step_of(s);
+      if (k >= 0) {
+        const int gs = __builtin_amdgcn_readlane(gsv, k), cs = __builtin_amdgcn_readlane(csv, k);
+        const bool last = k == L - 1, tojunc = ch == 0 && last && junc, has_next = !last || tojunc;
+        const d4 Ls = Ln, Sd = tojunc ? d4{0, 0, 0, 0} : Sn;
+        if (!last) chain_fetch(k + 1);
+        if (ch == 1 && last && junc) Dc += oc_ldS(scr + 4 * BLK, lane);
+#ifdef MPCQP_TIMING
+        const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+#endif
+        ok = oc_sweep(Dc, lane) && ok;
+#ifdef MPCQP_TIMING
+        if (t_sweep && wid == 0) *t_sweep += __builtin_amdgcn_s_memtime() - s0_;
+#endif
+        oc_stD(slab + (long)gs * BLK, lane, Dc);
+        if (HUB) oc_stS(scr + (2 * ch + (s & 1)) * BLK, lane, Dc);
+        if (has_next) {
+          const d4 Wt = oc_mm(Dc, Ls, d4{0, 0, 0, 0});
+          Wp = Wt; pend = cs;
+          const d4 acc = oc_mm(-Wt, Ls, Sd);
+          if (tojunc) oc_stS(scr + 4 * BLK, lane, acc); else Dc = acc;
+        }
+      }
+    } else if (HUB) {
+      const int kc = step_of(s), kh = step_of(s - 1);
+      if (kc >= 0) {       // operands of the helper's next step; L_kc is what the chain wave overwrites one phase from now
+        const bool last = kc == L - 1, tojunc = ch == 0 && last && junc;
+        if (!last || tojunc) Ln = oc_ldA(slab + (long)__builtin_amdgcn_readlane(csv, kc) * BLK, lane);
+        if (!last) Hn = oc_ldA(slab + (long)__builtin_amdgcn_readlane(hsv, kc + 1) * BLK, lane);
+      }
+      if (kh >= 0) {
+        const int hs = __builtin_amdgcn_readlane(hsv, kh);
+        const bool last = kh == L - 1, tojunc = ch == 0 && last && junc, has_next = !last || tojunc;
+        if (ch == 1 && last && junc) Hr += oc_ldS(scr + 5 * BLK, lane);
+        const d4 G = oc_ldS(scr + (2 * ch + ((s - 1) & 1)) * BLK, lane);
+        const d4 WhT = oc_mm(G, Hr, d4{0, 0, 0, 0});
+        oc_stA(slab + (long)hs * BLK, lane, WhT);
+        const d4 nW = -WhT;
+        Sh = oc_mm(nW, Hr, Sh);
+        if (has_next) {
+          const d4 acc = oc_mm(Lc, nW, tojunc ? d4{0, 0, 0, 0} : Hc);
+          if (tojunc) oc_stS(scr + 5 * BLK, lane, acc); else Hr = acc;
+        }
+      }
+      Lc = Ln; Hc = Hn;
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the loads of L have landed before the chain wave may store W over it
+    }
+    bsync<NW>();
+  }
+  if (!helper && pend >= 0) oc_stA(slab + (long)pend * BLK, lane, Wp);
+  if (HUB) {
+    if (helper) oc_stS(scr + (6 + ch) * BLK, lane, Sh);
+    bsync<NW>();
+    if (wid == 0) {
+      d4 Dh = oc_ldD(slab + (long)oc.ghub_src * BLK, lane) + oc_ldS(scr + 6 * BLK, lane) + oc_ldS(scr + 7 * BLK, lane);
+      ok = oc_sweep(Dh, lane) && ok;
+      oc_stD(slab + (long)oc.ghub_src * BLK, lane, Dh);
+    }
+  }
+  if (lane == 0) red[wid] = ok ? 1.0 : 0.0;
+  bsync<NW>();
+  bool all_ok = true;
+#pragma unroll
+  for (int w = 0; w < NW; w++) all_ok = all_ok && red[w] != 0.0;
+  bsync<NW>();
+  return all_ok;
 }
 
 // what a wave needs to know about its own positions p = wid + NW s, read once into scalar registers.  Every loop over s is

@@ -27,6 +27,7 @@ struct RCtx {
   const DevPlan *pl; const DevRes *rs; const mpcqp_settings *st; double *ws;
   double *BL, *TMP, *X, *Q, *R, *Z, *Y, *W, *RB, *RED;
   double c, cinv, rho; int unscale; int wid, lane;
+  const int *coA, *coAt, *coP;      // chunk offsets of the three ELL structures (on-chip mode: a copy in LDS -- every chunk of every sweep starts by reading two of them)
   unsigned long long fts[4];
 };
 
@@ -85,15 +86,70 @@ __device__ __forceinline__ double ell_chunk(const double *__restrict__ val, cons
   if (rem & 1) acc = ell_batch<MAXABS, 1>(vp, ip, in, acc);
   return acc;
 }
+// Ruiz equilibration, one sweep over A by rows for both norms: max_j |a_ij| d_j stays in the row's lane, and |a_ij| e_i goes to column
+// j's accumulator with an LDS atomic max on the bit pattern (non-negative doubles order like their bit patterns) -- A' is not read.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+template <int U>
+__device__ __forceinline__ double ell_batch_rc(const double *__restrict__ &vp, const int *__restrict__ &ip, const double *din, const double ei, double *colacc, double acc) {
+  double v[U]; int ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = fabs(vp[u * WAVE]); ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    acc = fmax(acc, v[u] * din[ix[u]]);
+    if (v[u] != 0.0) __hip_atomic_fetch_max((lds_u64 *)(colacc + ix[u]), (unsigned long long)__double_as_longlong(v[u] * ei), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  vp += U * WAVE; ip += U * WAVE;
+  return acc;
+}
+__device__ __forceinline__ double ell_chunk_rc(const double *__restrict__ val, const int *__restrict__ idx, const double *din, const double ei, double *colacc, const int s0, const int s1, const int lane) {
+  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
+  const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
+  double acc = 0.0;
+  int rem = s1 - s0;
+  for (; rem >= 8; rem -= 8) acc = ell_batch_rc<8>(vp, ip, din, ei, colacc, acc);
+  if (rem & 4) acc = ell_batch_rc<4>(vp, ip, din, ei, colacc, acc);
+  if (rem & 2) acc = ell_batch_rc<2>(vp, ip, din, ei, colacc, acc);
+  if (rem & 1) acc = ell_batch_rc<1>(vp, ip, din, ei, colacc, acc);
+  return acc;
+}
+// out[e] = f(value, index) over the slots of one chunk, 8 / 4 / 2 / 1 slots per batch with all loads of a batch issued before the first use.
+// INDIRECT: the value is gathered from the caller's array through the slot's source index (-1 = padding)
+template <bool INDIRECT, int U, class F>
+__device__ __forceinline__ void ell_map_batch(const double *&vp, const int *__restrict__ &sp, const double *in, const int *__restrict__ &ip, double *&op, F &f) {
+  double v[U]; int ix[U], sr[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { if (INDIRECT) sr[u] = sp[u * WAVE]; else v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+  if (INDIRECT) {
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = sr[u] >= 0 ? in[sr[u]] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) op[u * WAVE] = f(v[u], ix[u]);
+  if (INDIRECT) sp += U * WAVE; else vp += U * WAVE;
+  ip += U * WAVE; op += U * WAVE;
+}
+template <bool INDIRECT, class F>
+__device__ __forceinline__ void ell_map_chunk(const double *val, const int *__restrict__ src, const double *in, const int *__restrict__ idx, double *out,
+                                              const int s0, const int s1, const int lane, F &&f) {
+  // (val and out may be the same array: scaled in place)
+  const long o = (long)s0 * WAVE + lane;
+  const double *vp = val + o; const int *__restrict__ sp = src + o; const int *__restrict__ ip = idx + o; double *op = out + o;
+  int rem = s1 - s0;
+  for (; rem >= 8; rem -= 8) ell_map_batch<INDIRECT, 8>(vp, sp, in, ip, op, f);
+  if (rem & 4) ell_map_batch<INDIRECT, 4>(vp, sp, in, ip, op, f);
+  if (rem & 2) ell_map_batch<INDIRECT, 2>(vp, sp, in, ip, op, f);
+  if (rem & 1) ell_map_batch<INDIRECT, 1>(vp, sp, in, ip, op, f);
+}
 // ELL sweeps for the multi-wave kernels: wave `wid` takes chunks wid, wid + NW, ... (A 16-deep clamped full unroll
 // and a 4-lanes-per-row split were both measured slower on MI355X: spills / more latency rounds; see DESIGN.md.)
 template <int NW, int UMAX = 16, class F>
-__device__ __forceinline__ void ell_rows_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<false, UMAX>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
+__device__ __forceinline__ void ell_rows_w(const DevEll &E, const int *co, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<false, UMAX>(val, E.idx, in, co[c], co[c + 1], lane));
 }
 template <int NW, class F>
-__device__ __forceinline__ void ell_rowmax_w(const DevEll &E, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
-  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<true>(val, E.idx, in, E.chunk_off[c], E.chunk_off[c + 1], lane));
+__device__ __forceinline__ void ell_rowmax_w(const DevEll &E, const int *co, const double *__restrict__ val, const double *in, int wid, int lane, F &&f) {
+  for (int c = wid; c < E.nchunks; c += NW) f(c * WAVE + lane, ell_chunk<true>(val, E.idx, in, co[c], co[c + 1], lane));
 }
 
 // sum over the 4 lanes of a quad with DPP quad_perm (no LDS crossbar round trip)
@@ -301,8 +357,9 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
   }
 }
 
-template <int NW>
-__device__ __forceinline__ bool factorize_res(RCtx &cx) {
+// OCM: 0 the level loop below; 1 / 2 the on-chip topology without / with an arrow head: kernel_onchip.hpp's oc_ldl on the assembled blocks
+template <int NW, int OCM = 0>
+__device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullptr, const int *octab = nullptr, double *scr = nullptr) {
   const DevPlan &pl = *cx.pl; const DevRes &rs = *cx.rs; double *ws = cx.ws;
   const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
   const double *lb = ws + pl.o_l, *ub = ws + pl.o_u;
@@ -312,14 +369,14 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
   unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
   for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) : 0.0;
-  for (long k = tid; k < (long)pl.nT * BLK; k += NT) T[k] = 0.0;
+  // (the T tiles' structural zeros were written once, at creation: only the non-zeros are refreshed below)
   bsync<NW>();
   {
     const double sigma = cx.st->sigma;
     const DevEll &E = pl.At;
     for (int c = wid; c < E.nchunks; c += NW) {
       double acc = 0.0;
-      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+      for (int s = cx.coAt[c]; s < cx.coAt[c + 1]; s++) {
         const unsigned e = (unsigned)s * WAVE + lane;
         const double v = valAt[e];
         if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
@@ -333,7 +390,7 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
     for (int c = wid; c < E.nchunks; c += NW) {
       const int i = c * WAVE + lane;
       const double sr = sqrt(cx.W[i]);
-      for (int s = E.chunk_off[c]; s < E.chunk_off[c + 1]; s++) {
+      for (int s = cx.coA[c]; s < cx.coA[c + 1]; s++) {
         const unsigned e = (unsigned)s * WAVE + lane;
         const int tp = pl.tpos[e];
         if (tp >= 0) T[tp] = valA[e] * sr;
@@ -362,6 +419,14 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
 #ifdef MPCQP_TIMING
   unsigned long long f2 = __builtin_amdgcn_s_memtime(); cx.fts[1] += f2 - f1;
 #endif
+  if constexpr (OCM > 0) {
+#ifdef MPCQP_TIMING
+    const bool okf = oc_ldl<NW, (OCM > 1)>(*oc, octab, cx.BL, scr, cx.RED, wid, lane, &cx.fts[3]);
+#else
+    const bool okf = oc_ldl<NW, (OCM > 1)>(*oc, octab, cx.BL, scr, cx.RED, wid, lane);
+#endif
+    if (!okf) return false;
+  } else {
   // right-looking block LDL' by elimination-tree levels: G_K = S_KK^-1 (one wave per column of the level);
   // W_IK = S_IK G_K into temp tiles; S_IJ -= W_IK S_JK' (same-destination updates on one wave); the W tiles replace
   // the S_IK slots one phase later, once every update that still needs S_JK has read it.
@@ -404,6 +469,7 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx) {
   }
   for (int a = wid; a < nprev; a += NW)   // (the last level has no off-diagonal block; kept for generality)
     reinterpret_cast<d4 *>(cx.BL + (long)rs.lw_slot[prev0 + a] * BLK)[lane] = reinterpret_cast<const d4 *>(cx.TMP + (long)a * BLK)[lane];
+  }
   if (rs.nconst) {   // the constant block -I that folds the partial sums of a split run into their destination
     double *ni = cx.BL + (long)pl.nblk * BLK;
     for (int e = tid; e < BLK; e += NT) ni[e] = (e / BS == e % BS) ? -1.0 : 0.0;
@@ -430,7 +496,7 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
 #pragma unroll
   for (int k = 0; k < 15; k++) v[k] = 0.0;
   // 0 pr 1 nz 2 nax 3 prs 4 nzs 5 naxs 6 dr 7 nq 8 naty 9 npx 10 drs 11 nqs 12 natys 13 npxs | 14 obj (sum)
-  ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) {
+  ell_rows_w<NW>(pl.A, cx.coA, valA, cx.X, wid, lane, [&](int i, double ax) {
     if (i < pl.m) {
       const double einv = unscale ? 1.0 / Eg[i] : 1.0, zi = cx.Z[i];
       v[0] = fmax(v[0], fabs(einv * (ax - zi))); v[2] = fmax(v[2], fabs(einv * ax)); v[1] = fmax(v[1], fabs(einv * zi));
@@ -440,8 +506,8 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
   // P x and A' y land on the same rows for a given wave (both chunked by wid), so no barrier is needed in between
   for (int c = wid; c < pl.P.nchunks; c += NW) {
     const int la = lane;
-    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, pl.P.chunk_off[c], pl.P.chunk_off[c + 1], la);
-    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, pl.At.chunk_off[c], pl.At.chunk_off[c + 1], la);
+    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, cx.coP[c], cx.coP[c + 1], la);
+    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, cx.coAt[c], cx.coAt[c + 1], la);
     const int t = c * WAVE + lane;
     if (t < pl.npad) {
       const double dinv = unscale ? 1.0 / Dg[t] : 1.0, qv = cx.Q[t], du = qv + px + aty;
@@ -480,7 +546,7 @@ __device__ __forceinline__ bool primal_infeasible_res(RCtx &cx, double eps) {
   bool res = false;
   if (nrm > eps && lhs < -eps * nrm) {
     double a[1] = {0.0};
-    ell_rows_w<NW>(pl.At, ws + pl.o_ellAt, cx.W, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
+    ell_rows_w<NW>(pl.At, cx.coAt, ws + pl.o_ellAt, cx.W, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
     block_combine<NW, 1, 0>(a, cx.RED, wid, lane);
     res = a[0] < eps * nrm;
   }
@@ -507,11 +573,11 @@ __device__ __forceinline__ bool dual_infeasible_res(RCtx &cx, double eps) {
   bool res = false;
   if (nrm > eps && qdx < -cs * eps * nrm) {
     double a[1] = {0.0};
-    ell_rows_w<NW>(pl.P, ws + pl.o_ellP, cx.R, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
+    ell_rows_w<NW>(pl.P, cx.coP, ws + pl.o_ellP, cx.R, wid, lane, [&](int t, double x) { if (t < pl.npad) a[0] = fmax(a[0], fabs(cx.unscale ? (1.0 / Dg[t]) * x : x)); });
     block_combine<NW, 1, 0>(a, cx.RED, wid, lane);
     if (a[0] < cs * eps * nrm) {
       double bad[1] = {0.0};
-      ell_rows_w<NW>(pl.A, ws + pl.o_ellA, cx.R, wid, lane, [&](int i, double x) {
+      ell_rows_w<NW>(pl.A, cx.coA, ws + pl.o_ellA, cx.R, wid, lane, [&](int i, double x) {
         if (i < pl.m) {
           if (cx.unscale) x = (1.0 / Eg[i]) * x;
           if ((ub[i] < Q_INFTY * Q_MIN_SCALING && x > eps * nrm) || (lb[i] > -Q_INFTY * Q_MIN_SCALING && x < -eps * nrm)) bad[0] = 1.0;
@@ -556,6 +622,13 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 // OCG > 0 (with GB): the on-chip solve of kernel_onchip.hpp -- the factorisation still works in the slab (its tiles and the temp
 // tiles are dead outside it), then the factor is brought on chip: LDS block slots + OCG inverse diagonal blocks and OCH hub blocks
 // per wave in registers.
+#ifdef MPCQP_TIMING_RUIZ
+#define RZ_T0 unsigned long long rz_ = __builtin_amdgcn_s_memtime()
+#define RZ_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rzacc[(k) - 4] += t_ - rz_; rz_ = t_; } while (0)
+#else
+#define RZ_T0
+#define RZ_T(k)
+#endif
 template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false, int OCG = 0, int OCH = 0>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -594,8 +667,17 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   cx.unscale = st.scaling && !st.scaled_termination;
 
   TS_DECL;
+#ifdef MPCQP_TIMING_RUIZ
+  unsigned long long rzacc[5] = {0, 0, 0, 0, 0};
+#endif
+  cx.coA = pl.A.chunk_off; cx.coAt = pl.At.chunk_off; cx.coP = pl.P.chunk_off;
   if constexpr (OC) {
     for (int k = tid; k < oc.o_pos; k += NT) octab[k] = oc.tab[k];      // the chain tables; the rest is only read when the factor is loaded
+    int *co = octab + ((oc.o_pos + 1) & ~1);                            // ... and the chunk offsets: a slab round trip less at the head of every chunk
+    for (int k = tid; k <= pl.A.nchunks; k += NT) co[k] = pl.A.chunk_off[k];
+    for (int k = tid; k <= pl.At.nchunks; k += NT) co[pl.A.nchunks + 1 + k] = pl.At.chunk_off[k];
+    for (int k = tid; k <= pl.P.nchunks; k += NT) co[pl.A.nchunks + pl.At.nchunks + 2 + k] = pl.P.chunk_off[k];
+    cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
     ocl = oc_lane(lane);
   } else {
     for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
@@ -640,50 +722,65 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     // ---- load: caller's CSC values -> ELL arrays. The block region of LDS is idle until the factorisation, so the
     // ELL values of A, A', P live there for the whole scaling phase (host guarantees they fit) and are written to
     // the HBM slab once, already scaled.
-    double *sA = GB ? valA : lds, *sAt = GB ? valAt : sA + pl.A.entries, *sP = GB ? valP : sAt + pl.At.entries;
+    // (on-chip mode: the block slots hold A when it fits -- oc.a_lds, decided by the host -- and A', P are read from the slab)
+    const bool a_lds = OC && oc.a_lds;
+    const bool p_lds = OC && oc.p_lds;
+    double *sA = GB ? (a_lds ? lds : valA) : lds, *sAt = GB ? valAt : sA + pl.A.entries, *sP = GB ? (p_lds ? lds + pl.A.entries : valP) : sAt + pl.At.entries;
     for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
-    for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }
+    if (!GB) for (long e = tid; e < pl.At.entries; e += NT) { const int s = pl.At.src[e]; sAt[e] = s >= 0 ? inA[s] : 0.0; }   // (global-block kernels gather A' from the caller's array when they scale it)
     for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
-    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; }
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }
     for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
     bsync<NW>();
     for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
     bsync<NW>();
 
     TS(0);
-    // ---- modified Ruiz equilibration: D in R, E in W, temporaries in X / Z
+    // ---- modified Ruiz equilibration: D in R, E in W; X = the column-norm accumulators of the sweep over A; nP = max_k |P_tk| d_k of the
+    // current D is needed twice -- for this pass's column norm and, with the updated D, for the cost scaling, which is also the next
+    // pass's value -- and swept once per pass (it lives in y, which is idle until the iteration starts; in the slab when m < n)
     c = 1.0;
+    double *nPv = mpad >= npad ? cx.Y : ws + pl.o_dx;
+    if (st.scaling > 0) ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) nPv[t] = x; });
     for (int it = 0; it < st.scaling; it++) {
-      for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
-        const int t = ch * WAVE + lane;
-        const int la = lane;
-        const double nA = ell_chunk<true>(sAt, pl.At.idx, cx.W, pl.At.chunk_off[ch], pl.At.chunk_off[ch + 1], la);
-        const double nP = ell_chunk<true>(sP, pl.P.idx, cx.R, pl.P.chunk_off[ch], pl.P.chunk_off[ch + 1], la);
-        if (t < npad) { const double dj = cx.R[t]; cx.X[t] = 1.0 / sqrt(limit_scaling(fmax(c * dj * nP, dj * nA))); }
+      RZ_T0;
+      for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+        const int i = ch * WAVE + lane;
+        const double ei = i < mpad ? cx.W[i] : 0.0;
+        const double v = ell_chunk_rc(sA, pl.A.idx, cx.R, ei, cx.X, cx.coA[ch], cx.coA[ch + 1], lane);
+        if (i < mpad) cx.W[i] = ei * (1.0 / sqrt(limit_scaling(ei * v)));       // (e_i is read by its own lane only: updated in place)
       }
-      ell_rowmax_w<NW>(pl.A, sA, cx.R, wid, lane, [&](int i, double v) { if (i < mpad) cx.Z[i] = 1.0 / sqrt(limit_scaling(cx.W[i] * v)); });
+      RZ_T(4);
       bsync<NW>();
-      for (int t = tid; t < npad; t += NT) cx.R[t] *= cx.X[t];
-      for (int i = tid; i < mpad; i += NT) cx.W[i] *= cx.Z[i];
+      RZ_T(5);
+      for (int t = tid; t < npad; t += NT) {       // (the thread that wrote nPv[t])
+        const double dj = cx.R[t];
+        cx.R[t] = dj * (1.0 / sqrt(limit_scaling(fmax(c * dj * nPv[t], dj * cx.X[t]))));
+        cx.X[t] = 0.0;
+      }
       bsync<NW>();
+      RZ_T(6);
       double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
-      ell_rowmax_w<NW>(pl.P, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+      ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+      RZ_T(7);
       block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
       const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
       c *= ct;
       bsync<NW>();
+      RZ_T(8);
     }
     c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
     TS(1);
-    // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots)
+    // scale and write out: A <- E A D, A' likewise, P <- c D P D (coalesced stores of whole 512 B slots; the loads of up to 8 slots in flight)
     for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
-      const int i = ch * WAVE + lane; const double ei = cx.W[i];
-      for (int s = pl.A.chunk_off[ch]; s < pl.A.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valA[e] = sA[e] * (ei * cx.R[pl.A.idx[e]]); }
+      const int i = ch * WAVE + lane; const double ei = i < mpad ? cx.W[i] : 0.0;
+      ell_map_chunk<false>(sA, pl.A.idx, nullptr, pl.A.idx, valA, cx.coA[ch], cx.coA[ch + 1], lane, [&](double v, int j) { return v * (ei * cx.R[j]); });
     }
     for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
       const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
-      for (int s = pl.At.chunk_off[ch]; s < pl.At.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valAt[e] = sAt[e] * (dj * cx.W[pl.At.idx[e]]); }
-      for (int s = pl.P.chunk_off[ch]; s < pl.P.chunk_off[ch + 1]; s++) { const unsigned e = (unsigned)s * WAVE + lane; valP[e] = sP[e] * (c * dj * cx.R[pl.P.idx[e]]); }
+      // (global-block kernels gather A' from the caller's array here)
+      ell_map_chunk<GB>(sAt, pl.At.src, inA, pl.At.idx, valAt, cx.coAt[ch], cx.coAt[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
+      ell_map_chunk<false>(sP, pl.P.idx, nullptr, pl.P.idx, valP, cx.coP[ch], cx.coP[ch + 1], lane, [&](double v, int k) { return v * (c * dj * cx.R[k]); });
     }
     bsync<NW>();
     for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
@@ -701,7 +798,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; cx.X[t] = io.x0[(long)b * n + j] * (1.0 / Dg[t]); }
     for (int i = tid; i < m; i += NT) cx.Y[i] = io.y0[(long)b * m + i] * (1.0 / Eg[i]) * c;
     bsync<NW>();
-    ell_rows_w<NW>(pl.A, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
+    ell_rows_w<NW>(pl.A, cx.coA, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
     bsync<NW>();
   }
   // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
@@ -710,7 +807,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   Info in; memset(&in, 0, sizeof(in));
   TS(2);
   bool ok = !(reuse && prev_status == MPCQP_NON_CVX);
-  if (ok && refactor) ok = factorize_res<NW>(cx);
+  if (ok && refactor) ok = factorize_res<NW, (OC ? (OCH > 0 ? 2 : 1) : 0)>(cx, &oc, octab, ocBL);
   else if (ok) {   // kept factor: only w = rho z - y, which the factorisation leaves behind otherwise
     for (int i = tid; i < mpad; i += NT) cx.W[i] = i < m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
     bsync<NW>();
@@ -734,7 +831,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
-      ell_rows_w<NW, EU>(pl.At, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      ell_rows_w<NW, EU>(pl.At, cx.coAt, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
@@ -769,7 +866,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
           const double lo = lb[i], up = ub[i];
           // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
           const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
-          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, pl.A.chunk_off[c], pl.A.chunk_off[c + 1], lane);
+          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
@@ -804,7 +901,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         rn = fmin(fmax(rn, Q_RHO_MIN), Q_RHO_MAX);
         if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
           cx.rho = uni(rn);
-          if (!factorize_res<NW>(cx)) { status = MPCQP_NON_CVX; break; }
+          if (!factorize_res<NW, (OC ? (OCH > 0 ? 2 : 1) : 0)>(cx, &oc, octab, ocBL)) { status = MPCQP_NON_CVX; break; }
           if constexpr (OC) oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
         }
       }
@@ -834,6 +931,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   TS(8);
 #ifdef MPCQP_TIMING
   ts_acc[12] = cx.fts[0]; ts_acc[13] = cx.fts[1]; ts_acc[14] = cx.fts[2]; ts_acc[15] = cx.fts[3];
+#ifdef MPCQP_TIMING_RUIZ
+  ts_acc[9] = rzacc[0]; ts_acc[10] = rzacc[1]; ts_acc[11] = rzacc[2]; ts_acc[12] = rzacc[3]; ts_acc[13] = rzacc[4];
+#endif
 #endif
   TS_STORE(io.dbg);
 }

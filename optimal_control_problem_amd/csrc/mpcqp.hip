@@ -270,7 +270,11 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const ResPlan r4 = build_res_plan(p4, 4, false);
       h->oc = false;
       const OcPlan o = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();
-      if (o.ok && lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) { h->ocplan = o; h->oc = true; }
+      if (o.ok && lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) {
+        h->ocplan = o; h->oc = true;
+        // same ordering and blocks, ELL widths for this instance's 8 slots in flight (plan.hpp build_ell pad = 2)
+        if (!getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
+      }
       if (!h->oc && want == 4 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc4")
         return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));
     }
@@ -328,7 +332,9 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const OcPlan &o = h->ocplan; DevOc &d = h->doc;
       dr.stage = oc_stage_doubles(o, rp); dr.rext = OC_REXT; dr.nconst = 0; dr.n_seg = 0;
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
-      d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot;
+      d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
+      d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
+      d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));
     }
   }
@@ -336,6 +342,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
   dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.o_Zg = w.Zg; dp.o_Yg = w.Yg; dp.ws_stride = w.stride;
   UP(dalloc(h, &h->ws, (size_t)w.stride * batch));
+  // the resident kernels only ever write the structural non-zeros of the T tiles (fixed positions, plan.hpp tpos): their zeros are set here, once
+  UP([&]() -> int { HIPCHK(hipMemset(h->ws, 0, (size_t)w.stride * batch * sizeof(double))); HIPCHK(hipStreamSynchronize(0)); return MPCQP_OK; }());
   UP(dalloc(h, &h->ox, (size_t)batch * n)); UP(dalloc(h, &h->oy, (size_t)batch * std::max(m, 1))); UP(dalloc(h, &h->oz, (size_t)batch * std::max(m, 1)));
   UP(dalloc(h, &h->oinfo, (size_t)batch * 4)); UP(dalloc(h, &h->ocs, (size_t)batch));
   UP(dalloc(h, &h->ostatus, (size_t)batch)); UP(dalloc(h, &h->oiters, (size_t)batch));

@@ -41,7 +41,10 @@ struct EllEntry { int idx, src, flag; };
 
 // pad4: round chunk widths above 2 up to a multiple of 4 (zero entries) so that the latency-bound resident kernels
 // need fewer load batches per chunk (17 slots = 16 + 4 instead of 8 + 8 + 1); the streaming kernel keeps exact widths
-inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows, bool pad4 = false) {
+// pad = 2: for the kernels that keep 8 slots in flight -- round a width up (by at most 3) only where that saves a load batch of the
+// 8 / 4 / 2 / 1 decomposition (14 -> 16: two batches instead of three; 17 stays: three either way, and 15 % fewer bytes than 20)
+inline int ell_batches8(int w) { int r = w % 8; return w / 8 + (r & 1) + ((r >> 1) & 1) + ((r >> 2) & 1); }
+inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows, int pad4 = 0) {
   Ell e;
   e.nrows = (int)rows.size();
   e.nchunks = (e.nrows + WAVE - 1) / WAVE;
@@ -49,7 +52,8 @@ inline Ell build_ell(const std::vector<std::vector<EllEntry>> &rows, bool pad4 =
   for (int c = 0; c < e.nchunks; c++) {
     size_t w = 0;
     for (int r = c * WAVE; r < std::min(e.nrows, (c + 1) * WAVE); r++) w = std::max(w, rows[r].size());
-    if (pad4 && w > 2) w = (w + 3) / 4 * 4;
+    if (pad4 == 1 && w > 2) w = (w + 3) / 4 * 4;
+    if (pad4 == 2 && w > 2) { size_t best = w; for (size_t w2 = w + 1; w2 <= w + 3; w2++) if (ell_batches8((int)w2) < ell_batches8((int)best)) best = w2; w = best; }
     e.chunk_off[c + 1] = e.chunk_off[c] + (int)w;
   }
   e.idx.assign(e.entries(), 0); e.src.assign(e.entries(), -1); e.flag.assign(e.entries(), 0);
@@ -153,7 +157,7 @@ inline int block_fill(int nb, std::vector<std::set<int>> &pat) {
 }  // namespace detail
 
 // Build the plan. P: CSC n x n (entries with row > col ignored), A: CSC m x n.
-inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1, bool pad4 = false) {
+inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1, int pad4 = 0) {
   Plan pl;
   pl.n = n; pl.m = m;
   if (n <= 0 || m < 0 || !Pp || !Ap) { pl.error = "invalid dimensions"; return pl; }
@@ -764,9 +768,10 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
 }
 // LDS of the on-chip variant: block slots (the factorisation's temp tiles and the staged ELL values alias them), x, q, r (+ the
 // junction / hub partial sums) [npad], z, y, w [mpad], reduction scratch, the table
-inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp) { return (long)std::max(oc.nlds, rp.ntemp) * BLK; }
+inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp) { return (long)std::max(std::max(oc.nlds, rp.ntemp), 8) * BLK; }   // (8: the scratch blocks of the in-register factorisation, kernel_onchip.hpp OC_LDL_SCR)
 inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc) {
-  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4;      // the chain tables live in LDS; the per-position and fill tables are read from global memory
+  // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
+  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1) / 2;
   return (oc_stage_doubles(oc, rp) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 

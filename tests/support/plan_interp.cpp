@@ -368,7 +368,132 @@ Wave zero() { Wave w; std::memset(&w, 0, sizeof(w)); return w; }
 Wave add(Wave a, const Wave &b) { for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) a.v[l][i] += b.v[l][i]; return a; }
 }  // namespace
 
-extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH,
+// kernel_onchip.hpp oc_ldl: the in-register block LDL' of the chain + hub topology, wave by wave and phase by phase, on the slab S of assembled
+// blocks; layouts D(X): lane 16 kk + n holds X[kk + 4 g][n], A(X) = D(X'); a hazard = two waves touching a slab block or a scratch block in one
+// phase with at least one of them writing.  returns 0 ok, 2 not positive definite, 3 hazard
+namespace {
+Wave ldD(const double *b) { Wave w; for (int l = 0; l < 64; l++) for (int g = 0; g < 4; g++) w.v[l][g] = b[((l >> 4) + 4 * g) * BS + (l & 15)]; return w; }
+void stD(double *b, const Wave &w) { for (int l = 0; l < 64; l++) for (int g = 0; g < 4; g++) b[((l >> 4) + 4 * g) * BS + (l & 15)] = w.v[l][g]; }
+Wave ldA(const double *b) { Wave w; for (int l = 0; l < 64; l++) for (int g = 0; g < 4; g++) w.v[l][g] = b[(l & 15) * BS + (l >> 4) + 4 * g]; return w; }
+void stA(double *b, const Wave &w) { for (int l = 0; l < 64; l++) for (int g = 0; g < 4; g++) b[(l & 15) * BS + (l >> 4) + 4 * g] = w.v[l][g]; }
+Wave neg(Wave a) { for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) a.v[l][i] = -a.v[l][i]; return a; }
+bool sweep_d(Wave &a) {
+  bool ok = true;
+  for (int k = 0; k < BS; k++) {
+    const int g = k >> 2, ks = k & 3;
+    const double d = a.v[16 * ks + k][g];
+    ok = ok && d > 0.0;
+    const double p = 1.0 / d;
+    double w[64], bw[64];
+    for (int l = 0; l < 64; l++) {
+      const bool grp = (l >> 4) == ks, colk = (l & 15) == k;
+      w[l] = grp ? (colk ? -1.0 : a.v[l][g]) : 0.0; bw[l] = -p * w[l];
+      if (grp) a.v[l][g] = 0.0;
+      if (colk) for (int gg = 0; gg < 4; gg++) a.v[l][gg] = 0.0;
+    }
+    mfma(w, bw, a);
+  }
+  a = neg(a);
+  return ok;
+}
+int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
+  const int *tab = oc.tab.data();
+  const int LE = tab[0], LF = tab[1];
+  const bool junc = oc.junc && LF > 0;
+  const int Sph = junc ? std::max(LE + 1, LF) : LE;
+  const int *pt = tab + oc.o_pos;
+  std::vector<double> scr(8 * BLK, 0.0);
+  struct St { Wave Dc, Wp, Hr, Lc, Ln, Sn, Hc, Hn, Sh; int pend; bool ok; } st[4];
+  for (auto &x : st) { x.Dc = x.Wp = x.Hr = x.Lc = x.Ln = x.Sn = x.Hc = x.Hn = x.Sh = zero(); x.pend = -1; x.ok = true; }
+  const int nblk = (int)(S.size() / BLK);
+  std::vector<int> wr(nblk + 8, -1), rd(nblk + 8, 0);
+  bool hazard = false;
+  auto touch = [&](int w, int blk, bool write) {
+    if (wr[blk] >= 0 && wr[blk] != w) hazard = true;
+    if (write) { if (rd[blk] & ~(1 << w)) hazard = true; wr[blk] = w; } else rd[blk] |= 1 << w;
+  };
+  auto barrier = [&]() { std::fill(wr.begin(), wr.end(), -1); std::fill(rd.begin(), rd.end(), 0); };
+  auto SB = [&](int b) { return &S[(size_t)b * BLK]; };
+  auto SC = [&](int b) { return &scr[(size_t)b * BLK]; };
+  const int nph = HUB ? Sph + 1 : Sph;
+  for (int s = -1; s < nph; s++) {                       // s = -1: the fetches ahead of the first phase
+    for (int wid = 0; wid < 4; wid++) {
+      const int ch = wid & 1; const bool helper = wid >= 2;
+      const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
+      auto step_of = [&](int q) -> int { if (q < 0) return -1; if (ch == 0) return q < LE ? q : -1; if (q < LF - 1) return q; return (q == Sph - 1 && LF > 0) ? LF - 1 : -1; };
+      auto gsv = [&](int k) { return pt[5 * tab[cb + 2 * k]]; };
+      auto csv = [&](int k) { return pt[5 * tab[cb + 2 * k] + 1]; };
+      auto hsv = [&](int k) { return pt[5 * tab[cb + 2 * k] + 2]; };
+      St &x = st[wid];
+      auto chain_fetch = [&](int k) {
+        const bool last = k == L - 1, tojunc = ch == 0 && last && junc;
+        if (!last || tojunc) { touch(wid, csv(k), false); x.Ln = ldA(SB(csv(k))); }
+        if (!last) { touch(wid, gsv(k + 1), false); x.Sn = ldD(SB(gsv(k + 1))); }
+      };
+      if (s < 0) {
+        if (L > 0) {
+          if (!helper) { touch(wid, gsv(0), false); x.Dc = ldD(SB(gsv(0))); chain_fetch(0); }
+          else if (HUB) { touch(wid, hsv(0), false); x.Hr = ldA(SB(hsv(0))); }
+        }
+        continue;
+      }
+      if (!helper) {
+        if (x.pend >= 0) { touch(wid, x.pend, true); stA(SB(x.pend), x.Wp); x.pend = -1; }
+        const int k = step_of(s);
+        if (k < 0) continue;
+        const int gs = gsv(k), cs = csv(k);
+        const bool last = k == L - 1, tojunc = ch == 0 && last && junc, has_next = !last || tojunc;
+        const Wave Ls = x.Ln, Sd = tojunc ? zero() : x.Sn;
+        if (!last) chain_fetch(k + 1);
+        if (ch == 1 && last && junc) { touch(wid, nblk + 4, false); x.Dc = add(x.Dc, ldD(SC(4))); }
+        x.ok = sweep_d(x.Dc) && x.ok;
+        touch(wid, gs, true); stD(SB(gs), x.Dc);
+        if (HUB) { touch(wid, nblk + 2 * ch + (s & 1), true); stD(SC(2 * ch + (s & 1)), x.Dc); }
+        if (has_next) {
+          Wave Wt = zero(); mv(x.Dc, Ls, Wt);
+          x.Wp = Wt; x.pend = cs;
+          Wave acc = Sd; mv(neg(Wt), Ls, acc);
+          if (tojunc) { touch(wid, nblk + 4, true); stD(SC(4), acc); } else x.Dc = acc;
+        }
+      } else if (HUB) {
+        const int kc = step_of(s), kh = step_of(s - 1);
+        if (kc >= 0) {
+          const bool last = kc == L - 1, tojunc = ch == 0 && last && junc;
+          if (!last || tojunc) { touch(wid, csv(kc), false); x.Ln = ldA(SB(csv(kc))); }
+          if (!last) { touch(wid, hsv(kc + 1), false); x.Hn = ldA(SB(hsv(kc + 1))); }
+        }
+        if (kh >= 0) {
+          const int hs = hsv(kh);
+          const bool last = kh == L - 1, tojunc = ch == 0 && last && junc, has_next = !last || tojunc;
+          if (ch == 1 && last && junc) { touch(wid, nblk + 5, false); x.Hr = add(x.Hr, ldD(SC(5))); }
+          touch(wid, nblk + 2 * ch + ((s - 1) & 1), false);
+          const Wave G = ldD(SC(2 * ch + ((s - 1) & 1)));
+          Wave WhT = zero(); mv(G, x.Hr, WhT);
+          touch(wid, hs, true); stA(SB(hs), WhT);
+          const Wave nW = neg(WhT);
+          mv(nW, x.Hr, x.Sh);
+          if (has_next) { Wave acc = tojunc ? zero() : x.Hc; mv(x.Lc, nW, acc); if (tojunc) { touch(wid, nblk + 5, true); stD(SC(5), acc); } else x.Hr = acc; }
+        }
+        x.Lc = x.Ln; x.Hc = x.Hn;
+      }
+    }
+    if (s >= 0) barrier();                               // (no barrier between the fetches ahead and phase 0)
+  }
+  for (int wid = 0; wid < 2; wid++) if (st[wid].pend >= 0) { touch(wid, st[wid].pend, true); stA(SB(st[wid].pend), st[wid].Wp); }
+  bool ok = st[0].ok && st[1].ok;
+  if (HUB) {
+    stD(SC(6), st[2].Sh); stD(SC(7), st[3].Sh);
+    barrier();
+    Wave Dh = add(add(ldD(SB(oc.ghub_src)), ldD(SC(6))), ldD(SC(7)));
+    ok = sweep_d(Dh) && ok;
+    stD(SB(oc.ghub_src), Dh);
+  }
+  if (hazard) return 3;
+  return ok ? 0 : 2;
+}
+}  // namespace
+
+extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH, int ldl,
                                const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
   const int nw = 4;
   Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, true);
@@ -403,6 +528,11 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
       if (pl.blk_diag[b] >= 0 && row == col) C[row * BS + col] += dvec[pl.blk_diag[b] * BS + row];
     }
   }
+  if (ldl) {
+    if ((NH > 0) != (oc.has_hub != 0)) return 5;
+    const int rcl = emu_oc_ldl(oc, S, NH > 0);
+    if (rcl) return rcl;
+  } else {
   std::vector<int> pend_slot, pend_tmp;
   for (int lev = 0; lev < rp.nlev; lev++) {
     for (int ci = rp.lv_ptr[lev]; ci < rp.lv_ptr[lev + 1]; ci++) if (!sweep_inverse(&S[(size_t)rp.lv_diag[ci] * BLK])) return 2;
@@ -417,6 +547,7 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
     for (int a = 0; a < nwk; a++) { pend_slot.push_back(rp.lw_slot[w0 + a]); pend_tmp.push_back(a); }
   }
   for (size_t a = 0; a < pend_slot.size(); a++) std::memcpy(&S[(size_t)pend_slot[a] * BLK], &tmp[(size_t)pend_tmp[a] * BLK], BLK * sizeof(double));
+  }
   // ---- oc_load_factor: LDS images (negated off-diagonal blocks, swizzled) and per-wave register blocks
   const int *tab = oc.tab.data();
   std::vector<double> BL((size_t)oc.nlds * BLK, 0.0);
@@ -516,5 +647,18 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   }
   if (hazard) return 3;
   for (int j = 0; j < n; j++) sol[j] = R[pl.pos[j]];
+  return 0;
+}
+
+// chunk widths of the three ELL structures (diagnostic): out = [nA, widths..., nAt, widths..., nP, widths...]
+extern "C" int plan_ell_widths(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int pad4, int *out, int cap) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, pad4 != 0);
+  if (!pl.error.empty()) return 1;
+  int k = 0;
+  for (const Ell *e : {&pl.A, &pl.At, &pl.P}) {
+    if (k + 1 + e->nchunks > cap) return 2;
+    out[k++] = e->nchunks;
+    for (int c = 0; c < e->nchunks; c++) out[k++] = e->chunk_off[c + 1] - e->chunk_off[c];
+  }
   return 0;
 }

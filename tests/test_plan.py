@@ -155,7 +155,7 @@ def test_slab_layout_and_schedule_bounds(built, name, N):
                 assert L.plan_check_segments(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), nw + 100 * (force + 1) + split, _p(info)) == 0
 
 
-def _run_oc(ls, NG=5, NH=3, b=0, seed=0):
+def _run_oc(ls, NG=5, NH=3, b=0, seed=0, ldl=1):
     """the on-chip plan (plan.hpp build_oc_plan) through the lane-accurate emulation of kernel_onchip.hpp's solve in plan_interp.cpp:
     MFMA operand layouts, phi, swizzled LDS images read as rows and columns, chain tables, phantom slots, junction and hub phases"""
     L = C.CDLL(SO)
@@ -167,7 +167,7 @@ def _run_oc(ls, NG=5, NH=3, b=0, seed=0):
     M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
     rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(8, np.int64)
     Pv = np.ascontiguousarray(np.broadcast_to(ls.P, (ls.batch, len(ls.Pi)))[b]); Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[b])
-    rc = L.plan_execute_oc(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), NG, NH, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
+    rc = L.plan_execute_oc(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), NG, NH, ldl, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
     if rc == 0:
         ref = np.linalg.solve(M, rhs)
         assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
@@ -178,9 +178,10 @@ def _run_oc(ls, NG=5, NH=3, b=0, seed=0):
                                            ("quadrotor", 12, dict(nbc=12, has_hub=1, junc=1, nhr=3)),              # phantom slots (12 positions, 5 per wave)
                                            ("cartpole", 30, dict(has_hub=1, junc=0)),                             # one chain, the hub shares the last block
                                            ("double_integrator", 20, dict(has_hub=1, junc=0))])
-def test_onchip_plan_emulated(built, name, N, expect):
+@pytest.mark.parametrize("ldl", [0, 1])      # the factor from the level loop / from the in-register LDL' (oc_ldl), both emulated
+def test_onchip_plan_emulated(built, name, N, expect, ldl):
     mdl, ls, _ = models.make_workload(name, 2, N=N)
-    rc, info = _run_oc(ls, b=1)
+    rc, info = _run_oc(ls, b=1, ldl=ldl)
     assert rc == 0, (rc, info)
     for k, v in expect.items():
         assert info[k] == v, (k, info)
