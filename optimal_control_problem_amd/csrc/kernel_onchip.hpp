@@ -28,6 +28,7 @@ struct DevOc {
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
+  const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
 };
 
 // LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart

@@ -357,6 +357,25 @@ __device__ __forceinline__ void run_schedule(const int4 *segs, const int g0, con
   }
 }
 
+// factorisation set-up loops over ELL slots, 8 / 4 / 2 / 1 per batch with every load of a batch issued before the first use
+template <int U>
+__device__ __forceinline__ void dvec_batch(const double *&vp, const int *&fp, const int *&ip, const double *w, double &acc) {
+  double v[U]; int fl[U], ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; fl[u] = fp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) if (fl[u]) acc += w[ix[u]] * v[u] * v[u];
+  vp += U * WAVE; fp += U * WAVE; ip += U * WAVE;
+}
+template <int U>
+__device__ __forceinline__ void tscatter_batch(const double *&vp, const int *&tp, double *T, const double sr) {
+  double v[U]; int t[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; t[u] = tp[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) if (t[u] >= 0) T[t[u]] = v[u] * sr;
+  vp += U * WAVE; tp += U * WAVE;
+}
 // OCM: 0 the level loop below; 1 / 2 the on-chip topology without / with an arrow head: kernel_onchip.hpp's oc_ldl on the assembled blocks
 template <int NW, int OCM = 0>
 __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullptr, const int *octab = nullptr, double *scr = nullptr) {
@@ -372,15 +391,19 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
   // (the T tiles' structural zeros were written once, at creation: only the non-zeros are refreshed below)
   bsync<NW>();
   {
+    // d_t = sigma + sum_i rho_i a_it^2 over the singleton rows of column t (the rest of A' rho A goes through the T tiles)
     const double sigma = cx.st->sigma;
     const DevEll &E = pl.At;
     for (int c = wid; c < E.nchunks; c += NW) {
       double acc = 0.0;
-      for (int s = cx.coAt[c]; s < cx.coAt[c + 1]; s++) {
-        const unsigned e = (unsigned)s * WAVE + lane;
-        const double v = valAt[e];
-        if (E.flag[e]) acc += cx.W[E.idx[e]] * v * v;
-      }
+      const int s0 = cx.coAt[c], s1 = cx.coAt[c + 1];
+      const long o = (long)s0 * WAVE + lane;
+      const double *vp = valAt + o; const int *fp = E.flag + o, *ip = E.idx + o;
+      int rem = s1 - s0;
+      for (; rem >= 8; rem -= 8) dvec_batch<8>(vp, fp, ip, cx.W, acc);
+      if (rem & 4) dvec_batch<4>(vp, fp, ip, cx.W, acc);
+      if (rem & 2) dvec_batch<2>(vp, fp, ip, cx.W, acc);
+      if (rem & 1) dvec_batch<1>(vp, fp, ip, cx.W, acc);
       const int t = c * WAVE + lane;
       if (t < pl.npad) cx.R[t] = pl.perm[t] >= 0 ? sigma + acc : 1.0;
     }
@@ -390,18 +413,80 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
     for (int c = wid; c < E.nchunks; c += NW) {
       const int i = c * WAVE + lane;
       const double sr = sqrt(cx.W[i]);
-      for (int s = cx.coA[c]; s < cx.coA[c + 1]; s++) {
-        const unsigned e = (unsigned)s * WAVE + lane;
-        const int tp = pl.tpos[e];
-        if (tp >= 0) T[tp] = valA[e] * sr;
-      }
+      const int s0 = cx.coA[c], s1 = cx.coA[c + 1];
+      const long o = (long)s0 * WAVE + lane;
+      const double *vp = valA + o; const int *tp = pl.tpos + o;
+      int rem = s1 - s0;
+      for (; rem >= 8; rem -= 8) tscatter_batch<8>(vp, tp, T, sr);
+      if (rem & 4) tscatter_batch<4>(vp, tp, T, sr);
+      if (rem & 2) tscatter_batch<2>(vp, tp, T, sr);
+      if (rem & 1) tscatter_batch<1>(vp, tp, T, sr);
     }
+  }
+  int *rec = nullptr;
+  if constexpr (OCM > 0) {      // the assembly recipe of every block, one 32-byte record each, next to the factorisation's scratch blocks
+    rec = reinterpret_cast<int *>(scr + OC_LDL_SCR * BLK);
+    for (int k = tid; k < 8 * pl.nblk; k += NT) rec[k] = oc->asm_rec[k];
   }
   bsync<NW>();
 #ifdef MPCQP_TIMING
   unsigned long long f1 = __builtin_amdgcn_s_memtime(); cx.fts[0] += f1 - f0;
 #endif
   const int row0 = lane >> 4, col = lane & 15;
+  if constexpr (OCM > 0) {
+    // S_b = sum_g T_a(g) T_b(g)' + P entries + the diagonal, three blocks in flight per wave: while block b multiplies, the T tiles of the
+    // wave's next block and its P values are on their way, and the P indices of the one after that (every stage a slab round trip that the
+    // loop used to wait for, block after block)
+    // Every fetch is unconditional -- unused terms read the zero tile behind the T tiles, a block past the wave's last one is fetched again --
+    // so the loop body is straight-line code and the compiler's wait counts stay exact (a conditional load makes it wait for everything)
+    const int nblk = pl.nblk;
+    auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto fetch_ops = [&](const int bb, d4 (&A)[3], d4 (&B)[3], int &n, int &J) {
+      const int4 r0 = *reinterpret_cast<const int4 *>(rec + 8 * bb), r1 = *reinterpret_cast<const int4 *>(rec + 8 * bb + 4);
+      n = rfl(r0.x); J = rfl(r0.y);
+      A[0] = oc_ldA(T + (long)rfl(r0.z) * BLK, lane); B[0] = oc_ldA(T + (long)rfl(r0.w) * BLK, lane);
+      if (n > 1) { A[1] = oc_ldA(T + (long)rfl(r1.x) * BLK, lane); B[1] = oc_ldA(T + (long)rfl(r1.y) * BLK, lane); }
+      if (n > 2) { A[2] = oc_ldA(T + (long)rfl(r1.z) * BLK, lane); B[2] = oc_ldA(T + (long)rfl(r1.w) * BLK, lane); }
+    };
+    auto fetch_pidx = [&](const int bb, int (&pi)[4]) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) pi[g] = pl.asm_pidx[(long)bb * BLK + g * WAVE + lane];
+    };
+    if (wid < nblk) {
+      const int bl = wid + (nblk - 1 - wid) / NW * NW;       // the wave's last block
+      // two register sets in turn (no copy of a register with a load in flight): while one block multiplies, the other set is being filled
+      d4 A0[3], B0[3], A1[3], B1[3];
+      int n0, J0, n1, J1, pin[4];
+      double pv0[4], pv1[4]; bool m0[4], m1[4];
+      auto gather = [&](double (&pv)[4], bool (&mk)[4]) {       // P values of the block whose indices sit in pin; then pin moves on
+#pragma unroll
+        for (int g = 0; g < 4; g++) { pv[g] = valP[max(pin[g], 0)]; mk[g] = pin[g] >= 0; }
+      };
+      auto finish = [&](const int bb, const d4 (&A)[3], const d4 (&B)[3], const int n, const int J, const double (&pv)[4], const bool (&mk)[4]) {
+        d4 acc = {0, 0, 0, 0};
+        acc = oc_mm(A[0], B[0], acc);
+        if (n > 1) acc = oc_mm(A[1], B[1], acc);
+        if (n > 2) acc = oc_mm(A[2], B[2], acc);
+        if (n > 3) for (int g = pl.asm_ptr[bb] + 3; g < pl.asm_ptr[bb + 1]; g++) acc = mfma_abt_l(T + (long)pl.asm_a[g] * BLK, T + (long)pl.asm_b[g] * BLK, acc, lane);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (mk[g]) acc[g] += pv[g];
+          const int row = row0 + 4 * g;
+          if (J >= 0 && row == col) acc[g] += cx.R[J * BS + row];
+          cx.BL[(long)bb * BLK + row * BS + col] = acc[g];
+        }
+      };
+      fetch_ops(wid, A0, B0, n0, J0); fetch_pidx(wid, pin);
+      gather(pv0, m0); fetch_pidx(min(wid + NW, bl), pin);
+      for (int b = wid; b < nblk; b += 2 * NW) {
+        const int b1 = min(b + NW, bl), b2 = min(b + 2 * NW, bl), b3 = min(b + 3 * NW, bl);     // (past the end: the last block once more, same result)
+        fetch_ops(b1, A1, B1, n1, J1); gather(pv1, m1); fetch_pidx(b2, pin);
+        finish(b, A0, B0, n0, J0, pv0, m0);
+        fetch_ops(b2, A0, B0, n0, J0); gather(pv0, m0); fetch_pidx(b3, pin);
+        finish(b1, A1, B1, n1, J1, pv1, m1);
+      }
+    }
+  } else {
   for (int b = wid; b < pl.nblk; b += NW) {
     d4 acc = {0, 0, 0, 0};
     for (int g = pl.asm_ptr[b]; g < pl.asm_ptr[b + 1]; g++) acc = mfma_abt_l(T + (long)pl.asm_a[g] * BLK, T + (long)pl.asm_b[g] * BLK, acc, lane);
@@ -414,6 +499,7 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
       if (J >= 0 && row == col) acc[g] += cx.R[J * BS + row];
       cx.BL[(long)b * BLK + row * BS + col] = acc[g];
     }
+  }
   }
   bsync<NW>();
 #ifdef MPCQP_TIMING
@@ -637,9 +723,23 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   static_assert(!OC || (GB && !ZYG && NW == 4), "the on-chip solve is a mode of the 4-wave global-block kernel");
   constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
   constexpr int EU = OC ? 8 : 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower; the on-chip mode needs the registers)
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (OC) {
+    // Which wave plays which part is free.  The two workgroups of a CU put their chain waves (0, 1: the only ones busy in the chain phases of
+    // the solve, bound by dependent MFMAs) on different SIMDs: the wave on SIMD s of the workgroup in LDS slot k takes part (s + 2 k) mod 4.
+    // HW_ID[5:4] = SIMD, LDS_ALLOC[7:0] = LDS base (0: the CU's first slot).  Only when the four waves do sit on four SIMDs.
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    const int simd = (hw >> 4) & 3, slot = (la & 0xff) != 0;
+    int *xs = reinterpret_cast<int *>(lds);
+    if (lane == 0) xs[wid] = simd;
+    bsync<NW>();
+    const int seen = (1 << xs[0]) | (1 << xs[1]) | (1 << xs[2]) | (1 << xs[3]);
+    bsync<NW>();
+    if (seen == 15 && !io.no_remap) wid = __builtin_amdgcn_readfirstlane((simd + 2 * slot) & 3);
+  }
+  const int tid = wid * WAVE + lane;
   RCtx cx;
   cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
   cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
@@ -861,12 +961,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         // l, u are fetched before the row sum is accumulated; rho_i and 1/rho_i are selected from the three values
         // the rho rule can produce (no per-row division).
         const double rho_eq = uni(Q_RHO_EQ * cx.rho), ri_min = 1.0 / Q_RHO_MIN, ri_eq = uni(1.0 / rho_eq), ri_in = uni(1.0 / cx.rho);
-        for (int c = wid; c < pl.A.nchunks; c += NW) {
-          const int i = c * WAVE + lane;
-          const double lo = lb[i], up = ub[i];
-          // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
-          const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
-          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
+        auto row_update = [&](const int i, const double lo, const double up, const double zo, const double yp, const double zt) {
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
@@ -876,6 +971,14 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
             cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
             if (save) dyg[i] = dy;
           }
+        };
+        for (int c = wid; c < pl.A.nchunks; c += NW) {
+          const int i = c * WAVE + lane;
+          const double lo = lb[i], up = ub[i];
+          // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
+          const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
+          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
+          row_update(i, lo, up, zo, yp, zt);
         }
       }
       bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on

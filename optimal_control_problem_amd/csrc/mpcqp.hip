@@ -330,12 +330,13 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     memset(&h->doc, 0, sizeof(h->doc));
     if (h->oc) {
       const OcPlan &o = h->ocplan; DevOc &d = h->doc;
-      dr.stage = oc_stage_doubles(o, rp); dr.rext = OC_REXT; dr.nconst = 0; dr.n_seg = 0;
+      dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = OC_REXT; dr.nconst = 0; dr.n_seg = 0;
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));
+      UP(upload(h, oc_asm_records(pl), &d.asm_rec));
     }
   }
   const WsLayout &w = h->wl;
@@ -563,7 +564,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (h->inner) return solve_reduced(h, s);
   DevIO io = h->io;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
@@ -642,7 +643,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
   DevIO io = h->io;
   io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = 0; io.keep = h->keep ? 1 : 0; io.order = nullptr;
   if (sP == 0 && wP) HIPCHK(hipMemcpy(h->dP, P, wP * sizeof(double), hipMemcpyHostToDevice));      // shared matrices: once
   if (sA == 0 && wA) HIPCHK(hipMemcpy(h->dA, A, wA * sizeof(double), hipMemcpyHostToDevice));

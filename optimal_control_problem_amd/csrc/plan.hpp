@@ -391,7 +391,7 @@ inline WsLayout ws_layout(const Plan &pl) {
   auto take = [&](long cnt) { long r = o; o += (cnt + 15) / 16 * 16; return r; };
   w.ellA = take(pl.A.entries()); w.ellAt = take(pl.At.entries()); w.ellP = take(pl.P.entries());
   w.Lf = take(((long)pl.nblk + 1) * BLK);   // + the constant -I block of split runs
-  w.Lb = take((long)pl.nblk * BLK); w.T = take((long)std::max(pl.nT, 1) * BLK);
+  w.Lb = take((long)pl.nblk * BLK); w.T = take(((long)std::max(pl.nT, 1) + 1) * BLK);   // + a tile of zeros (never written after creation)
   w.l = take(pl.mpad); w.u = take(pl.mpad); w.D = take(pl.npad); w.E = take(pl.mpad);
   w.dx = take(pl.npad); w.dy = take(pl.mpad);
   w.Zg = take(pl.mpad); w.Yg = take(pl.mpad);   // z, y of the kernels that keep them out of LDS (row-indexed only, like l and u)
@@ -768,11 +768,23 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
 }
 // LDS of the on-chip variant: block slots (the factorisation's temp tiles and the staged ELL values alias them), x, q, r (+ the
 // junction / hub partial sums) [npad], z, y, w [mpad], reduction scratch, the table
-inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp) { return (long)std::max(std::max(oc.nlds, rp.ntemp), 8) * BLK; }   // (8: the scratch blocks of the in-register factorisation, kernel_onchip.hpp OC_LDL_SCR)
+inline std::vector<int> oc_asm_records(const Plan &pl) {
+  std::vector<int> r((size_t)8 * pl.nblk, std::max(pl.nT, 1));      // unused terms: the zero tile behind the T tiles (ws_layout)
+  for (int b = 0; b < pl.nblk; b++) {
+    const int p0 = pl.asm_ptr[b], n = pl.asm_ptr[b + 1] - p0;
+    r[8 * b] = n; r[8 * b + 1] = pl.blk_diag[b];
+    for (int t = 0; t < std::min(n, 3); t++) { r[8 * b + 2 + 2 * t] = pl.asm_a[p0 + t]; r[8 * b + 3 + 2 * t] = pl.asm_b[p0 + t]; }
+  }
+  return r;
+}
+inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp, const Plan &pl) {
+  // block slots / temp tiles, or the factorisation's scratch: 8 hand-over blocks + the assembly records (4 doubles per block)
+  return std::max((long)std::max(oc.nlds, rp.ntemp) * BLK, 8L * BLK + ((4L * pl.nblk + 15) / 16) * 16);   // (8: kernel_onchip.hpp OC_LDL_SCR)
+}
 inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc) {
   // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
   const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1) / 2;
-  return (oc_stage_doubles(oc, rp) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
+  return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {

@@ -662,3 +662,18 @@ extern "C" int plan_ell_widths(int n, int m, const int *Pp, const int *Pi, const
   }
   return 0;
 }
+
+// assembly recipe statistics (diagnostic): out = [nT, nblk, total gemm terms, max terms per block, blocks with P entries]
+extern "C" int plan_asm_stats(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int *out) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, true);
+  if (!pl.error.empty()) return 1;
+  int mx = 0, withp = 0;
+  for (int b = 0; b < pl.nblk; b++) {
+    mx = std::max(mx, pl.asm_ptr[b + 1] - pl.asm_ptr[b]);
+    bool hp = false; for (int e = 0; e < BLK; e++) if (pl.asm_pidx[(size_t)b * BLK + e] >= 0) hp = true;
+    withp += hp;
+  }
+  out[0] = pl.nT; out[1] = pl.nblk; out[2] = pl.asm_ptr[pl.nblk]; out[3] = mx; out[4] = withp;
+  for (int b = 0; b < pl.nblk && b < 100; b++) out[5 + b] = pl.asm_ptr[b + 1] - pl.asm_ptr[b];
+  return 0;
+}
