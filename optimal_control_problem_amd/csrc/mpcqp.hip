@@ -260,7 +260,16 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         // factor streamed from the slab, two waves per QP (168-VGPR instance, six workgroups per CU) while six fit the LDS: ahead of four waves x
         // four workgroups there (double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB
         // and above four waves win)
-        else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) { want = 2; h->gblocks = true; }
+        else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) {
+          want = 2; h->gblocks = true;
+          // ... unless the on-chip mode takes the pattern and the two sweeps over A and A' are the heavy part of an iteration (slots per chain
+          // block; measured, profiles/r02_variant_grid_onchip.txt: 12-state quadrotor N = 10 / 12 / 15 at 8.5 - 7.9 slots per block +8 / +9 / +15 %
+          // over the two-wave kernel; cart-pole N = 40 / 50 at 5.1 and double integrator N = 60 at 2.7: -9 / -4 / -13 %)
+          if (!getenv("MPCQP_NO_OC")) {
+            const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
+            if (o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX && 2L * (p4.A.slots() + p4.At.slots()) >= 13L * o.nbc) { want = 4; h->oc = true; }
+          }
+        }
         else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; h->oc = !getenv("MPCQP_NO_OC"); }
         else want = 0;
       }
