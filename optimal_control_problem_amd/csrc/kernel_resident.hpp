@@ -444,9 +444,11 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
     auto fetch_ops = [&](const int bb, d4 (&A)[3], d4 (&B)[3], int &n, int &J) {
       const int4 r0 = *reinterpret_cast<const int4 *>(rec + 8 * bb), r1 = *reinterpret_cast<const int4 *>(rec + 8 * bb + 4);
       n = rfl(r0.x); J = rfl(r0.y);
-      A[0] = oc_ldA(T + (long)rfl(r0.z) * BLK, lane); B[0] = oc_ldA(T + (long)rfl(r0.w) * BLK, lane);
-      if (n > 1) { A[1] = oc_ldA(T + (long)rfl(r1.x) * BLK, lane); B[1] = oc_ldA(T + (long)rfl(r1.y) * BLK, lane); }
-      if (n > 2) { A[2] = oc_ldA(T + (long)rfl(r1.z) * BLK, lane); B[2] = oc_ldA(T + (long)rfl(r1.w) * BLK, lane); }
+      // (both tiles of a product as row pieces T[row][4 kk .. 4 kk + 3]: one 32-byte read per lane, the k index of MFMA i being 4 kk + i for both)
+      const int o = (lane & 15) * BS + 4 * (lane >> 4);
+      A[0] = *reinterpret_cast<const d4 *>(T + (long)rfl(r0.z) * BLK + o); B[0] = *reinterpret_cast<const d4 *>(T + (long)rfl(r0.w) * BLK + o);
+      if (n > 1) { A[1] = *reinterpret_cast<const d4 *>(T + (long)rfl(r1.x) * BLK + o); B[1] = *reinterpret_cast<const d4 *>(T + (long)rfl(r1.y) * BLK + o); }
+      if (n > 2) { A[2] = *reinterpret_cast<const d4 *>(T + (long)rfl(r1.z) * BLK + o); B[2] = *reinterpret_cast<const d4 *>(T + (long)rfl(r1.w) * BLK + o); }
     };
     auto fetch_pidx = [&](const int bb, int (&pi)[4]) {
 #pragma unroll
