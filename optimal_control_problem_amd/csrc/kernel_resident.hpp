@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
-      ell_rows_w<NW, EU>(pl.At, cx.coAt, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      ell_rows_w<NW, (OC ? 16 : EU)>(pl.At, cx.coAt, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
           const double lo = lb[i], up = ub[i];
           // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
           const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
-          const double zt = ell_chunk<false, EU>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
+          const double zt = ell_chunk<false, (OC ? 16 : EU)>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
           row_update(i, lo, up, zo, yp, zt);
         }
       }

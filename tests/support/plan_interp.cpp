@@ -677,3 +677,14 @@ extern "C" int plan_asm_stats(int n, int m, const int *Pp, const int *Pi, const 
   for (int b = 0; b < pl.nblk && b < 100; b++) out[5 + b] = pl.asm_ptr[b + 1] - pl.asm_ptr[b];
   return 0;
 }
+
+// chain tables of the on-chip plan (diagnostic): out = [LE, LF, junc, chainE positions..., chainF positions...]
+extern "C" int plan_oc_chains(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int *out) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, true);
+  if (!pl.error.empty()) return 1;
+  OcPlan oc = build_oc_plan(pl, 4, 1 << 20, 5, 3);
+  if (!oc.ok) return 5;
+  int k = 0; out[k++] = (int)oc.chainE.size(); out[k++] = (int)oc.chainF.size(); out[k++] = oc.junc;
+  for (int p : oc.chainE) out[k++] = p; for (int p : oc.chainF) out[k++] = p;
+  return 0;
+}
