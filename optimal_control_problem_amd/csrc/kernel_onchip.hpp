@@ -26,6 +26,7 @@
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
+  int at_poll, at_free;   // chunks of A' whose rows the iteration computes during the chain phase instead of before it (-1: none); see oc_solve
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
   const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
@@ -321,10 +322,16 @@ __device__ __forceinline__ int2 oc_pair(const int *tab, int k) { return *reinter
 // Chain tables are {position, LDS slot of the block below it} pairs; the entries, blocks and right-hand sides of the next stage
 // are fetched while the current stage multiplies.  HUB: the pattern has an arrow head (has_hub); its first NH blocks per wave are
 // in registers (the host lays the plan out for exactly this instance).
-template <int NW, int NG, int NH, bool HUB>
+// Late rows of the right-hand side: the chains need the last vector blocks last, and waves 2, 3 are idle while they run.  So the sweep
+// over A' before the solve leaves out the chunk of the last chain positions (oc.at_poll) and the chunk of the hub's rows (oc.at_free, read
+// only after the barrier behind the chains); `late(wid)` computes them here, on wave 3 / wave 2.  The chain waves wait for wave 3's rows
+// at a fixed place -- the top of trip OC_POLL_TRIP, before any fetch of such a row (the host checks that: plan.hpp oc_late_chunks) -- on a
+// ticket in LDS that wave 3 sets to the iteration number once its rows are written.
+constexpr int OC_POLL_TRIP = 3;
+template <int NW, int NG, int NH, bool HUB, class Late>
 __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln, const OcWave<NG> &ow,
                                          const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
-                                         unsigned long long *stamp = nullptr) {
+                                         volatile int *ticket, const int iter, Late &&late, unsigned long long *stamp = nullptr) {
 #ifdef MPCQP_TIMING
 #define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -350,6 +357,10 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
 #pragma unroll
     for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
       if (k + 2 > nst) break;
+      if (trip == OC_POLL_TRIP && oc.at_poll >= 0) {     // the late rows of the right-hand side are in place from here on
+        while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       // stage k: y = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
       const d4 a1 = oc_ldF(BL + (long)e1.y * BLK, ln), c1 = oc_ldB(R, e2.x, ln);
       const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
@@ -370,6 +381,12 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     }
     // x = t of the chain's last position e0.x
     if (wid == 0 && oc.junc) oc_stB(EXT, 0, ln, oc_mv(oc_ldF(BL + (long)e0.y * BLK, ln), x, d4{0, 0, 0, 0}));
+  } else if (wid >= 2) {
+    late(wid);
+    if (wid == 3 && oc.at_poll >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (ln.col0 && ln.vb == 0) *ticket = iter;
+    }
   }
   bsync<NW>();
   OC_TS(0);

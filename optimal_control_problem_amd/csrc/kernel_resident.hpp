@@ -757,6 +757,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   cx.RB = cx.W + pl.mpad; cx.RED = cx.RB + 16 * NW + 16;
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 16 * NW);     // (block_combine needs 15 * NW) [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
+  volatile int *octicket = nullptr;                             // on-chip solve: wave 3's ticket for the late rows of the right-hand side
   int *octab = reinterpret_cast<int *>(cx.RED + 16 * NW) + 8;   // on-chip solve: its table (8-byte aligned pairs) instead of schedule segments
   double *ocBL = lds;                                           // ... and the LDS block slots (the temp tiles of the factorisation alias them)
   d4 ocG[OC ? OCG : 1], ocHF[OCH > 0 ? OCH : 1], ocHT[OCH > 0 ? OCH : 1];
@@ -780,6 +781,8 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     for (int k = tid; k <= pl.At.nchunks; k += NT) co[pl.A.nchunks + 1 + k] = pl.At.chunk_off[k];
     for (int k = tid; k <= pl.P.nchunks; k += NT) co[pl.A.nchunks + pl.At.nchunks + 2 + k] = pl.P.chunk_off[k];
     cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
+    octicket = co + pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3;
+    if (tid == 0) *octicket = 0;
     ocl = oc_lane(lane);
   } else {
     for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
@@ -930,18 +933,34 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   int can_check = 0;
   const int sq0 = OC ? 0 : lptr[wid], sq1 = OC ? 0 : lptr[wid + 1];
   const int ni_off = rs.nconst ? pl.nblk * BLK * 8 : -1;      // byte offset of the constant -I block (split accumulation runs)
+  // on-chip mode: the rows of the right-hand side that waves 2 / 3 compute while the chains run (kernel_onchip.hpp oc_solve)
+  auto late_rows = [&](const int w) {
+    const int c = w == 3 ? oc.at_poll : oc.at_free;
+    if (c >= 0) {
+      const int t = c * WAVE + lane;
+      const double v = ell_chunk<false, 16>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
+      if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
+    }
+  };
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
-      ell_rows_w<NW, (OC ? 16 : EU)>(pl.At, cx.coAt, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+      if constexpr (OC) {     // (the chunks named in oc.at_poll / oc.at_free are computed during the chain phase of the solve: oc_solve)
+        for (int c = wid; c < pl.At.nchunks; c += NW) if (c != oc.at_poll && c != oc.at_free) {
+          const int t = c * WAVE + lane;
+          const double v = ell_chunk<false, 16>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
+          if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
+        }
+      } else
+      ell_rows_w<NW, EU>(pl.At, cx.coAt, valAt, cx.W, wid, lane, [&](int t, double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
 #else
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid);
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows);
 #endif
       } else {
 #ifdef MPCQP_TIMING

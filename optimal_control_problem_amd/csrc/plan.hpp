@@ -768,6 +768,27 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
 }
 // LDS of the on-chip variant: block slots (the factorisation's temp tiles and the staged ELL values alias them), x, q, r (+ the
 // junction / hub partial sums) [npad], z, y, w [mpad], reduction scratch, the table
+// Which chunks of A' the iteration may compute late, during the chain phase of the solve (kernel_onchip.hpp oc_solve): with more than
+// four chunks some wave would sweep two before the solve starts.  A chunk past the fourth qualifies as `free` when all its rows belong to
+// the hub (read only behind the barrier that ends the chain phase), and as `poll` when all its rows are chain positions that neither chain
+// fetches before the top of trip poll_trip: by then a chain has fetched its entries 0 .. 2 poll_trip + 1.
+inline void oc_late_chunks(const Plan &pl, const OcPlan &oc, int nw, int poll_trip, int *at_poll, int *at_free) {
+  *at_poll = -1; *at_free = -1;
+  const int nc = pl.At.nchunks;
+  if (nc <= nw || nc > nw + 2) return;
+  int early = -1;                                    // highest position fetched before the poll
+  for (const std::vector<int> *ch : {&oc.chainE, &oc.chainF})
+    for (size_t i = 0; i < ch->size() && (int)i <= 2 * poll_trip + 1; i++) early = std::max(early, (*ch)[i]);
+  int poll = -1, fre = -1;
+  for (int c = nw; c < nc; c++) {
+    const int t0 = c * WAVE, t1 = std::min(pl.npad, t0 + WAVE);
+    const int p0 = t0 / BS, p1 = (t1 - 1) / BS;
+    if (p0 >= oc.nbc) { if (fre >= 0) return; fre = c; }
+    else if (p1 < oc.nbc && p0 > early) { if (poll >= 0) return; poll = c; }
+    else return;
+  }
+  *at_poll = poll; *at_free = fre;
+}
 inline std::vector<int> oc_asm_records(const Plan &pl) {
   std::vector<int> r((size_t)8 * pl.nblk, std::max(pl.nT, 1));      // unused terms: the zero tile behind the T tiles (ws_layout)
   for (int b = 0; b < pl.nblk; b++) {
@@ -783,7 +804,7 @@ inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp, const Plan &pl
 }
 inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc) {
   // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
-  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1) / 2;
+  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1 + 1) / 2;     // (+ the ticket of the late right-hand side rows)
   return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 
