@@ -322,16 +322,25 @@ __device__ __forceinline__ int2 oc_pair(const int *tab, int k) { return *reinter
 // Chain tables are {position, LDS slot of the block below it} pairs; the entries, blocks and right-hand sides of the next stage
 // are fetched while the current stage multiplies.  HUB: the pattern has an arrow head (has_hub); its first NH blocks per wave are
 // in registers (the host lays the plan out for exactly this instance).
+// Touch every 128-byte line of [base, base + bytes): one dword per lane and line, results dropped -- brings a slab region that the next
+// phase streams into L2 while this wave has nothing else to do (the wave waits for its own loads: nothing outstanding when it moves on)
+__device__ __forceinline__ void oc_touch(const void *base, const long bytes, const int lane) {
+  const char *p = reinterpret_cast<const char *>(base) + (long)lane * 128;
+  for (long o = 0; o < bytes; o += 64 * 128) {
+    if (o + (long)lane * 128 < bytes) { int t; asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(p + o) : "memory"); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // Late rows of the right-hand side: the chains need the last vector blocks last, and waves 2, 3 are idle while they run.  So the sweep
 // over A' before the solve leaves out the chunk of the last chain positions (oc.at_poll) and the chunk of the hub's rows (oc.at_free, read
 // only after the barrier behind the chains); `late(wid)` computes them here, on wave 3 / wave 2.  The chain waves wait for wave 3's rows
 // at a fixed place -- the top of trip OC_POLL_TRIP, before any fetch of such a row (the host checks that: plan.hpp oc_late_chunks) -- on a
 // ticket in LDS that wave 3 sets to the iteration number once its rows are written.
 constexpr int OC_POLL_TRIP = 3;
-template <int NW, int NG, int NH, bool HUB, class Late>
+template <int NW, int NG, int NH, bool HUB, class Late, class Idle>
 __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln, const OcWave<NG> &ow,
                                          const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
-                                         volatile int *ticket, const int iter, Late &&late, unsigned long long *stamp = nullptr) {
+                                         volatile int *ticket, const int iter, Late &&late, Idle &&idle, unsigned long long *stamp = nullptr) {
 #ifdef MPCQP_TIMING
 #define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -451,7 +460,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
       }
       if (k == 0) oc_stB(R, e0.x, ln, oc_mv(a, x, c));
     }
-  }
+  } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();
 #undef OC_TS
 }

@@ -942,6 +942,13 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
     }
   };
+  // ... and what they do while the chains run backwards: pull the values of A, l, u -- streamed right after the solve -- and of A' -- at
+  // the start of the next iteration -- into L2 (every iteration re-reads them, and 512 resident QPs x 90 KB do not stay in L2 by themselves)
+  auto idle_touch = [&](const int w) {
+    if (io.no_touch) return;
+    if (w == 2) oc_touch(valA, pl.A.entries * 8, lane);
+    else { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
+  };
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
@@ -958,9 +965,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
 #else
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows);
+        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
 #endif
       } else {
 #ifdef MPCQP_TIMING

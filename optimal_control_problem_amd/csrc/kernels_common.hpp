@@ -30,6 +30,7 @@ struct DevIO {
   double *ws; double *cscale; long long *dbg;
   const int *order;    // dispatch order: workgroup g solves instance order[g] (NULL = identity); see mpcqp_order_kernel
   int reuse, keep;     // kept workspace: skip scaling + factorisation (mpcqp_update_vectors) / store the factor for that
+  int no_touch;        // on-chip mode, experiment switch (MPCQP_NO_TOUCH): no L2 prefetch by the idle waves
   int no_remap;        // on-chip mode, experiment switch (MPCQP_NO_REMAP): waves keep the parts their index gives them
 };
 

@@ -575,7 +575,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (h->inner) return solve_reduced(h, s);
   DevIO io = h->io;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = getenv("MPCQP_NO_TOUCH") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
@@ -654,7 +654,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
   DevIO io = h->io;
   io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = getenv("MPCQP_NO_TOUCH") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = 0; io.keep = h->keep ? 1 : 0; io.order = nullptr;
   if (sP == 0 && wP) HIPCHK(hipMemcpy(h->dP, P, wP * sizeof(double), hipMemcpyHostToDevice));      // shared matrices: once
   if (sA == 0 && wA) HIPCHK(hipMemcpy(h->dA, A, wA * sizeof(double), hipMemcpyHostToDevice));
