@@ -263,7 +263,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) {
           want = 2; h->gblocks = true;
           // ... unless the on-chip mode takes the pattern and the two sweeps over A and A' are the heavy part of an iteration (slots per chain
-          // block; measured, profiles/r02_variant_grid_onchip.txt: 12-state quadrotor N = 10 / 12 / 15 at 8.5 - 7.9 slots per block +8 / +9 / +15 %
+          // block; measured, profiles/r02_final_variant_grid.txt: 12-state quadrotor N = 10 / 12 / 15 at 8.5 - 7.9 slots per block +11 / +12 / +20 %
           // over the two-wave kernel; cart-pole N = 40 / 50 at 5.1 and double integrator N = 60 at 2.7: -9 / -4 / -13 %)
           if (!getenv("MPCQP_NO_OC")) {
             const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
