@@ -46,18 +46,23 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 struct OcLane {
   int fLo, fHi;      // doubles inside a swizzled LDS block: elements (phi(n), 4 kk + 0..1) and (phi(n), 4 kk + 2..3)
   int t0, t1, t2, t3;   // elements (4 kk + i, phi(n))
-  int gF;            // row-major offset of (phi(n), 4 kk): A-operand reads from the slab
-  int gT;            // row-major offset of (4 kk, phi(n)); row i is + 16 i
   int vb;            // 4 kk: this lane group's piece of a vector block
-  bool col0;         // n == 0: the lane whose vector stores count
+  // the 4-block MFMA of the hub / diagonal phases (oc_mv4 below): row r4 = lane & 15, k4 = lane >> 4
+  int f4[4];         // elements (r4, k4 + 4 K) of a swizzled LDS block, K = 0..3
+  int t4[4];         // elements (k4 + 4 K, r4)
+  int k4;            // this lane's piece of a vector: v[k4 + 4 K]
+  int o4;            // the element of the result this lane holds: 4 ((lane >> 2) & 3) + (lane >> 4)
+  bool col0;         // n == 0 (lane & 15 == 0)
 };
 __device__ __forceinline__ OcLane oc_lane(int lane) {
   OcLane ln;
   const int n = lane & 15, kk = lane >> 4, r = oc_phi(n);
   ln.fLo = oc_swz(r, 4 * kk); ln.fHi = oc_swz(r, 4 * kk + 2);
   ln.t0 = oc_swz(4 * kk, r); ln.t1 = oc_swz(4 * kk + 1, r); ln.t2 = oc_swz(4 * kk + 2, r); ln.t3 = oc_swz(4 * kk + 3, r);
-  ln.gF = r * BS + 4 * kk; ln.gT = 4 * kk * BS + r;
   ln.vb = 4 * kk; ln.col0 = n == 0;
+#pragma unroll
+  for (int K = 0; K < 4; K++) { ln.f4[K] = oc_swz(n, kk + 4 * K); ln.t4[K] = oc_swz(kk + 4 * K, n); }
+  ln.k4 = kk; ln.o4 = 4 * ((lane >> 2) & 3) + (lane >> 4);
   return ln;
 }
 __device__ __forceinline__ d4 oc_ldF(const double *blk, const OcLane &ln) {
@@ -77,6 +82,17 @@ __device__ __forceinline__ d4 oc_mv(const d4 a, const d4 v, d4 acc) {
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], v[3], acc, 0, 0, 0);
   return acc;
 }
+// The hub and diagonal phases multiply independent blocks by independent vectors, and a 16x16x4 MFMA spends 64 cycles of the matrix pipe on each
+// of its four steps whether one column carries data or sixteen.  v_mfma_f64_4x4x4_4b_f64 -- four blocks of 4x4x4 per instruction, one double
+// per lane and operand -- issues every 20 cycles when independent (52 dependent; tools/probes/mfma_4x4_probe.hip, which also gave the layout:
+// A lane l <-> (i = l & 3, block = (l >> 2) & 3, k = l >> 4), B lane (j, block, k), D lane (j, block, i = l >> 4)).  For out = W v, block b of
+// step K takes the tile W[4 b .. + 3][4 K .. + 3] and the piece v[4 K .. + 3] in every column: lane l supplies W[l & 15][(l >> 4) + 4 K] and
+// v[(l >> 4) + 4 K], and receives out[4 ((l >> 2) & 3) + (l >> 4)].  Several such products run interleaved (oc_mv4 is one step of one of them).
+__device__ __forceinline__ double oc_mv4(const double a, const double v, const double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, v, acc, 0, 0, 0); }
+__device__ __forceinline__ d4 oc_ldF4(const double *blk, const OcLane &ln) { return d4{blk[ln.f4[0]], blk[ln.f4[1]], blk[ln.f4[2]], blk[ln.f4[3]]}; }
+__device__ __forceinline__ d4 oc_ldT4(const double *blk, const OcLane &ln) { return d4{blk[ln.t4[0]], blk[ln.t4[1]], blk[ln.t4[2]], blk[ln.t4[3]]}; }
+__device__ __forceinline__ d4 oc_ldB4(const double *vec, int p, const OcLane &ln) { const double *q = vec + BS * p + ln.k4; return d4{q[0], q[4], q[8], q[12]}; }
+__device__ __forceinline__ void oc_stB4(double *vec, int p, const OcLane &ln, const double v) { vec[BS * p + ln.o4] = v; }      // (the four lanes of a quad store the same value)
 __device__ __forceinline__ int oc_tab(const int *tab, int k) { return __builtin_amdgcn_readfirstlane(tab[k]); }
 
 // After a factorisation (or on a kept workspace): bring the factor from the slab on chip.  Off-diagonal blocks are stored
@@ -100,12 +116,15 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
     if (s < NH) { HF[s] = d4{0, 0, 0, 0}; HT[s] = d4{0, 0, 0, 0}; }
     if (p < oc.nbc) {
       const int gs = oc_tab(tab, oc.o_pos + 5 * p), hs = oc_tab(tab, oc.o_pos + 5 * p + 2);
-      G[s] = *reinterpret_cast<const d4 *>(slab + (long)gs * BLK + ln.gF);
+      // (operands of the 4-block MFMA: the block, resp. its transpose, as row lane & 15, columns (lane >> 4) + 4 K)
+      const int oA = (lane & 15) * BS + (lane >> 4), oD = (lane >> 4) * BS + (lane & 15);
+      const double *gb = slab + (long)gs * BLK;
+      G[s] = d4{gb[oA], gb[oA + 4], gb[oA + 8], gb[oA + 12]};
       if (s < NH) {
         if (hs >= 0) {
           const double *hb = slab + (long)hs * BLK;
-          HF[s] = -*reinterpret_cast<const d4 *>(hb + ln.gF);
-          HT[s] = -d4{hb[ln.gT], hb[ln.gT + BS], hb[ln.gT + 2 * BS], hb[ln.gT + 3 * BS]};
+          HF[s] = -d4{hb[oA], hb[oA + 4], hb[oA + 8], hb[oA + 12]};
+          HT[s] = -d4{hb[oD], hb[oD + 4 * BS], hb[oD + 8 * BS], hb[oD + 12 * BS]};
         }
       }
     }
@@ -400,40 +419,94 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
   bsync<NW>();
   OC_TS(0);
   if (f >= 0 && wid == (f & (NW - 1))) oc_stB(R, f, ln, oc_ldB(R, f, ln) + oc_ldB(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
-  d4 xh = {0, 0, 0, 0};
+  d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand pieces (k4 + 4 K)
+  double xhd = 0.0;           // ... and as its element of the result (o4)
+  constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
   if (HUB) {
-    // ---- F2
-    d4 hacc = {0, 0, 0, 0};
+    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions
+    double hsum = 0.0;
+    {
+      d4 t[NA], a[NA]; double acc[NA];
 #pragma unroll
-    for (int s = 0; s < NG; s++) {
-      const d4 t = oc_ldB(R, ow.vpos[s], ln);
-      if (s < NH) hacc = oc_mv(HF[s < NH ? s : 0], t, hacc);
-      else hacc = oc_mv(oc_ldF(BL + (long)ow.hslot[s] * BLK, ln), t, hacc);
+      for (int s = 0; s < NA; s++) { t[s] = oc_ldB4(R, ow.vpos[s], ln); a[s] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s] = 0.0; }
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(a[s][K], t[s][K], acc[s]);
+#pragma unroll
+      for (int s = 0; s < NA; s++) hsum += acc[s];
     }
-    oc_stB(EXT, 1 + wid, ln, hacc);
-    bsync<NW>();
-    // ---- F3
-    d4 th = oc_ldB(R, H, ln);
+    if (NG > NA) {
+      d4 t[NG - NA > 0 ? NG - NA : 1], a[NG - NA > 0 ? NG - NA : 1]; double acc[NG - NA > 0 ? NG - NA : 1];
 #pragma unroll
-    for (int w = 0; w < NW; w++) th += oc_ldB(EXT, 1 + w, ln);
-    xh = oc_mv(oc_ldF(BL + (long)oc.ghub_slot * BLK, ln), th, d4{0, 0, 0, 0});
+      for (int s = NA; s < NG; s++) { t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); a[s - NA] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s - NA] = 0.0; }
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(a[s - NA][K], t[s - NA][K], acc[s - NA]);
+#pragma unroll
+      for (int s = NA; s < NG; s++) hsum += acc[s - NA];
+    }
+    oc_stB4(EXT, 1 + wid, ln, hsum);
+    bsync<NW>();
+    // ---- F3: t_hub, x_hub = G_hub t_hub on every wave; the result goes through LDS once to become an operand (every wave writes the same
+    // values to the junction block, which is free by now)
+    d4 th = oc_ldB4(R, H, ln);
+#pragma unroll
+    for (int w = 0; w < NW; w++) th += oc_ldB4(EXT, 1 + w, ln);
+    const d4 gh = oc_ldF4(BL + (long)oc.ghub_slot * BLK, ln);
+#pragma unroll
+    for (int K = 0; K < 4; K++) xhd = oc_mv4(gh[K], th[K], xhd);
+    oc_stB4(EXT, 0, ln, xhd);
+    xh = oc_ldB4(EXT, 0, ln);
   }
   OC_TS(1);
-  // ---- B1
+  // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
+  {
+    d4 t[NA], g[NA], h[NA]; double acc[NA];
 #pragma unroll
-  for (int s = 0; s < NG; s++) {
-    const d4 t = oc_ldB(R, ow.vpos[s], ln);
-    d4 d = oc_mv(G[s], t, d4{0, 0, 0, 0});
-    if (HUB) {
-      if (s < NH) d = oc_mv(HT[s < NH ? s : 0], xh, d);
-      else d = oc_mv(oc_ldT(BL + (long)ow.hslot[s] * BLK, ln), xh, d);
+    for (int s = 0; s < NA; s++) {
+      t[s] = oc_ldB4(R, ow.vpos[s], ln); g[s] = G[s]; acc[s] = 0.0;
+      if (HUB) h[s] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
     }
-    if (ow.ok[s]) oc_stB(R, ow.vpos[s], ln, d);
+#pragma unroll
+    for (int K = 0; K < 4; K++)
+#pragma unroll
+      for (int s = 0; s < NA; s++) acc[s] = oc_mv4(g[s][K], t[s][K], acc[s]);
+    if (HUB) {
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(h[s][K], xh[K], acc[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NA; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s]);
+  }
+  if (NG > NA) {
+    constexpr int NB = NG - NA > 0 ? NG - NA : 1;
+    d4 t[NB], g[NB], h[NB]; double acc[NB];
+#pragma unroll
+    for (int s = NA; s < NG; s++) {
+      t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); g[s - NA] = G[s]; acc[s - NA] = 0.0;
+      if (HUB) h[s - NA] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
+    }
+#pragma unroll
+    for (int K = 0; K < 4; K++)
+#pragma unroll
+      for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(g[s - NA][K], t[s - NA][K], acc[s - NA]);
+    if (HUB) {
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(h[s - NA][K], xh[K], acc[s - NA]);
+    }
+#pragma unroll
+    for (int s = NA; s < NG; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s - NA]);
   }
   bsync<NW>();
   OC_TS(2);
   // ---- B2
-  if (HUB && wid == NW - 1) oc_stB(R, H, ln, xh);     // only now: every wave has read the hub's right-hand side
+  if (HUB && wid == NW - 1) oc_stB4(R, H, ln, xhd);     // only now: every wave has read the hub's right-hand side
   if (wid < 2 && len > 0) {
     // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;

@@ -368,6 +368,36 @@ Wave zero() { Wave w; std::memset(&w, 0, sizeof(w)); return w; }
 Wave add(Wave a, const Wave &b) { for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) a.v[l][i] += b.v[l][i]; return a; }
 }  // namespace
 
+// v_mfma_f64_4x4x4_4b_f64 (layout probed on hardware, tools/probes/mfma_4x4_probe.hip): A lane (i = l & 3, block = (l >> 2) & 3, k = l >> 4),
+// B lane (j, block, k), D lane (j, block, i = l >> 4); one double per lane and operand
+namespace {
+struct Wave1 { double v[64]; };
+Wave1 zero1() { Wave1 w; std::memset(&w, 0, sizeof(w)); return w; }
+void mfma4(const double a[64], const double b[64], Wave1 &acc) {
+  for (int l = 0; l < 64; l++) {
+    const int j = l & 3, blk = (l >> 2) & 3, i = l >> 4;
+    double s = 0;
+    for (int k = 0; k < 4; k++) s += a[i + 4 * blk + 16 * k] * b[j + 4 * blk + 16 * k];
+    acc.v[l] += s;
+  }
+}
+void mv4(const Wave &a, const Wave &v, Wave1 &acc) {      // one product: the four steps K of oc_mv4
+  for (int K = 0; K < 4; K++) { double x[64], y[64]; for (int l = 0; l < 64; l++) { x[l] = a.v[l][K]; y[l] = v.v[l][K]; } mfma4(x, y, acc); }
+}
+Wave ldA4g(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) w.v[l][K] = sign * blk[(l & 15) * BS + (l >> 4) + 4 * K]; return w; }
+Wave ldD4g(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) w.v[l][K] = sign * blk[((l >> 4) + 4 * K) * BS + (l & 15)]; return w; }
+Wave ldF4(const double *blk) { Wave w; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) w.v[l][K] = blk[swz(l & 15, (l >> 4) + 4 * K)]; return w; }
+Wave ldT4(const double *blk) { Wave w; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) w.v[l][K] = blk[swz((l >> 4) + 4 * K, l & 15)]; return w; }
+Wave ldB4(const double *vec, int p) { Wave w; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) w.v[l][K] = vec[BS * p + (l >> 4) + 4 * K]; return w; }
+bool stB4(double *vec, int p, const Wave1 &d) {            // the four lanes of a quad store one value: they must agree
+  for (int l = 0; l < 64; l++) {
+    if (d.v[l] != d.v[l & ~3]) return false;
+    vec[BS * p + 4 * ((l >> 2) & 3) + (l >> 4)] = d.v[l];
+  }
+  return true;
+}
+}  // namespace
+
 // kernel_onchip.hpp oc_ldl: the in-register block LDL' of the chain + hub topology, wave by wave and phase by phase, on the slab S of assembled
 // blocks; layouts D(X): lane 16 kk + n holds X[kk + 4 g][n], A(X) = D(X'); a hazard = two waves touching a slab block or a scratch block in one
 // phase with at least one of them writing.  returns 0 ok, 2 not positive definite, 3 hazard
@@ -564,9 +594,9 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
     okp[w][s] = p < oc.nbc; vpos[w][s] = p < oc.nbc ? p : zero_blk;
     const int hs = tab[oc.o_pos + 5 * pe + 4]; hslot[w][s] = hs >= 0 ? hs : 0;
     if (p < oc.nbc) {
-      G[w][s] = ldFg(&S[(size_t)tab[oc.o_pos + 5 * p] * BLK], 1.0);
+      G[w][s] = ldA4g(&S[(size_t)tab[oc.o_pos + 5 * p] * BLK], 1.0);       // (operands of the 4-block MFMA of the hub / diagonal phases)
       const int hsrc = tab[oc.o_pos + 5 * p + 2];
-      if (s < NH && hsrc >= 0) { HF[w][s] = ldFg(&S[(size_t)hsrc * BLK], -1.0); HT[w][s] = ldTg(&S[(size_t)hsrc * BLK], -1.0); }
+      if (s < NH && hsrc >= 0) { HF[w][s] = ldA4g(&S[(size_t)hsrc * BLK], -1.0); HT[w][s] = ldD4g(&S[(size_t)hsrc * BLK], -1.0); }
     }
   }
   // ---- oc_solve
@@ -604,33 +634,42 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   barrier();
   if (f >= 0) { const int w = f & (nw - 1); touch(w, f, false); touch(w, ext0, false); Wave t = add(ldB(R.data(), f), ldB(EXT, 0)); touch(w, f, true); stB(R.data(), f, t); }
   std::vector<Wave> xh(nw, zero());
+  std::vector<Wave1> xhd(nw, zero1());
+  bool quads = true;
   if (HUB) {
     for (int w = 0; w < nw; w++) {
-      Wave hacc = zero();
-      for (int s = 0; s < NG; s++) {
+      Wave1 hsum = zero1();
+      for (int s = 0; s < NG; s++) {                          // (one accumulator per position on the device, summed in slot order: the same value up to rounding)
         touch(w, vpos[w][s], false);
-        const Wave t = ldB(R.data(), vpos[w][s]);
-        if (s < NH) mv(HF[w][s], t, hacc); else mv(ldF(&BL[(size_t)hslot[w][s] * BLK]), t, hacc);
+        const Wave t = ldB4(R.data(), vpos[w][s]);
+        Wave1 acc = zero1();
+        if (s < NH) mv4(HF[w][s], t, acc); else mv4(ldF4(&BL[(size_t)hslot[w][s] * BLK]), t, acc);
+        for (int l = 0; l < 64; l++) hsum.v[l] += acc.v[l];
       }
-      touch(w, ext0 + 1 + w, true); stB(EXT, 1 + w, hacc);
+      touch(w, ext0 + 1 + w, true); quads = stB4(EXT, 1 + w, hsum) && quads;
     }
     barrier();
     for (int w = 0; w < nw; w++) {
       touch(w, H, false);
-      Wave th = ldB(R.data(), H);
-      for (int v = 0; v < nw; v++) { touch(w, ext0 + 1 + v, false); th = add(th, ldB(EXT, 1 + v)); }
-      mv(ldF(&BL[(size_t)oc.ghub_slot * BLK]), th, xh[w]);
+      Wave th = ldB4(R.data(), H);
+      for (int v = 0; v < nw; v++) { touch(w, ext0 + 1 + v, false); th = add(th, ldB4(EXT, 1 + v)); }
+      mv4(ldF4(&BL[(size_t)oc.ghub_slot * BLK]), th, xhd[w]);
     }
+    // every wave stores the same x_hub to the junction block and reads it back as operand pieces (same data: not a hazard)
+    for (int w = 1; w < nw; w++) for (int l = 0; l < 64; l++) if (xhd[w].v[l] != xhd[0].v[l]) return 1;
+    quads = stB4(EXT, 0, xhd[0]) && quads;
+    for (int w = 0; w < nw; w++) xh[w] = ldB4(EXT, 0);
   }
   for (int w = 0; w < nw; w++) for (int s = 0; s < NG; s++) {
     touch(w, vpos[w][s], false);
-    const Wave t = ldB(R.data(), vpos[w][s]);
-    Wave d = zero(); mv(G[w][s], t, d);
-    if (HUB) { if (s < NH) mv(HT[w][s], xh[w], d); else mv(ldT(&BL[(size_t)hslot[w][s] * BLK]), xh[w], d); }
-    if (okp[w][s]) { touch(w, vpos[w][s], true); stB(R.data(), vpos[w][s], d); }
+    const Wave t = ldB4(R.data(), vpos[w][s]);
+    Wave1 d = zero1(); mv4(G[w][s], t, d);
+    if (HUB) { if (s < NH) mv4(HT[w][s], xh[w], d); else mv4(ldT4(&BL[(size_t)hslot[w][s] * BLK]), xh[w], d); }
+    if (okp[w][s]) { touch(w, vpos[w][s], true); quads = stB4(R.data(), vpos[w][s], d) && quads; }
   }
   barrier();
-  if (HUB) { touch(nw - 1, H, true); stB(R.data(), H, xh[nw - 1]); }
+  if (HUB) { touch(nw - 1, H, true); quads = stB4(R.data(), H, xhd[nw - 1]) && quads; }
+  if (!quads) return 1;
   for (int w = 0; w < 2; w++) {
     const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
     if (len == 0) continue;
@@ -686,5 +725,34 @@ extern "C" int plan_oc_chains(int n, int m, const int *Pp, const int *Pi, const 
   if (!oc.ok) return 5;
   int k = 0; out[k++] = (int)oc.chainE.size(); out[k++] = (int)oc.chainF.size(); out[k++] = oc.junc;
   for (int p : oc.chainE) out[k++] = p; for (int p : oc.chainF) out[k++] = p;
+  return 0;
+}
+
+// the on-chip plan's extras (diagnostic / tests): out = [at_poll, at_free, A widths ok under pad = 2 (max |width - exact| <= 3), records consistent]
+extern "C" int plan_oc_extras(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int *out) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, 2), px = build_plan(n, m, Pp, Pi, Ap, Ai, 2, 0);
+  if (!pl.error.empty() || !px.error.empty()) return 1;
+  OcPlan oc = build_oc_plan(pl, 4, 1 << 20, 5, 3);
+  if (!oc.ok) { oc = build_oc_plan(pl, 4, 1 << 20, 5, 0); if (!oc.ok) return 5; }
+  oc_late_chunks(pl, oc, 4, 3, &out[0], &out[1]);
+  int okw = 1;
+  for (const auto &pr : {std::make_pair(&pl.A, &px.A), std::make_pair(&pl.At, &px.At)})
+    for (int c = 0; c < pr.first->nchunks; c++) {
+      const int w = pr.first->chunk_off[c + 1] - pr.first->chunk_off[c], e = pr.second->chunk_off[c + 1] - pr.second->chunk_off[c];
+      if (w < e || w > e + 3 || ell_batches8(w) > ell_batches8(e) || (w > e && ell_batches8(w) >= ell_batches8(e))) okw = 0;
+    }
+  out[2] = okw;
+  const std::vector<int> rec = oc_asm_records(pl);
+  int okr = 1;
+  for (int b = 0; b < pl.nblk; b++) {
+    const int p0 = pl.asm_ptr[b], cnt = pl.asm_ptr[b + 1] - p0;
+    if (rec[8 * b] != cnt || rec[8 * b + 1] != pl.blk_diag[b]) okr = 0;
+    for (int t = 0; t < 3; t++) {
+      const int a = rec[8 * b + 2 + 2 * t], bb = rec[8 * b + 3 + 2 * t];
+      if (t < cnt) { if (a != pl.asm_a[p0 + t] || bb != pl.asm_b[p0 + t]) okr = 0; }
+      else if (a != std::max(pl.nT, 1) || bb != std::max(pl.nT, 1)) okr = 0;        // the zero tile behind the T tiles
+    }
+  }
+  out[3] = okr; out[4] = (int)(ws_layout(pl).T + ((long)std::max(pl.nT, 1) + 1) * BLK <= ws_layout(pl).l);
   return 0;
 }

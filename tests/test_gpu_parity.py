@@ -364,6 +364,34 @@ def test_onchip_is_the_default_for_the_north_star_size(built):
     mdl, ls, _ = models.make_workload("quadrotor", 2, N=20)
     qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
     assert info["variant"] == 204 and info["lds_bytes"] <= 80 * 1024
+    # ... and where the two-wave global-block kernel used to be taken and the sweeps over A, A' are heavy (mpcqp.hip selection rule);
+    # not for the small-block models at that size
+    mdl, ls, _ = models.make_workload("quadrotor", 2, N=10)
+    qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+    assert info["variant"] == 204
+    mdl, ls, _ = models.make_workload("cartpole", 2, N=40)
+    qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+    assert info["variant"] == 102
+
+
+@pytest.mark.parametrize("knob", ["MPCQP_NO_LATE", "MPCQP_NO_REMAP", "MPCQP_NO_TOUCH", "MPCQP_OC_PAD4"])
+def test_onchip_scheduling_knobs_change_no_result(built, monkeypatch, knob):
+    """which wave computes which rows of the right-hand side and when (late rows, ticket), which wave plays which part, the L2 touch: none of
+    it may change a bit of the output; the ELL padding only adds zero slots (same sums)"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "oc4")           # (a batch of 64 alone would take the LDS-resident kernel)
+    mdl, ls, _ = models.make_workload("quadrotor", 64, N=20)
+    def run():
+        qp = BatchQP(ls.n, ls.m, 64, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+        assert qp.plan_info()["variant"] == 204
+        qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); out = qp.get(); qp.close()
+        return out
+    ref = run()
+    monkeypatch.setenv(knob, "1")
+    got = run()
+    for key in ("x", "y", "z"):
+        assert np.array_equal(ref[key], got[key]), key
+    assert np.array_equal(ref["iters"], got["iters"]) and np.array_equal(ref["status"], got["status"])
 
 
 @pytest.mark.parametrize("variant", ["stream", "res1", "res2", "res4", "gres4", "gres2"])

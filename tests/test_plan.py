@@ -200,3 +200,17 @@ def test_onchip_plan_without_hub_and_limits(built):
     assert _run_oc(ls)[0] == 5
     assert _run_oc(problems.random_qp(40, 30, 3))[0] == 0            # three blocks: a dense pattern still is chain + hub
     assert _run_oc(problems.random_qp(120, 60, 3))[0] == 5           # eight dense blocks are not block tridiagonal + arrow
+
+
+@pytest.mark.parametrize("name,N,late", [("quadrotor", 20, (4, 5)),      # 5 1/4 chunks of A' on four waves: the last chain positions polled, the hub's rows free
+                                         ("quadrotor", 12, (-1, -1)),    # four chunks: nothing to move
+                                         ("cartpole", 30, (-1, -1))])
+def test_onchip_plan_extras(built, name, N, late):
+    """host-side pieces of the on-chip mode added with its set-up rewrite: which chunks of A' may be computed during the chain phase
+    (plan.hpp oc_late_chunks), the batch-aware ELL padding, the assembly records and the zero tile they point unused terms at"""
+    L = C.CDLL(SO)
+    mdl, ls, _ = models.make_workload(name, 1, N=N)
+    out = np.zeros(8, np.int32)
+    assert L.plan_oc_extras(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), _p(out)) == 0
+    assert (out[0], out[1]) == late
+    assert out[2] == 1 and out[3] == 1 and out[4] == 1
