@@ -93,6 +93,22 @@ __device__ __forceinline__ d4 oc_ldF4(const double *blk, const OcLane &ln) { ret
 __device__ __forceinline__ d4 oc_ldT4(const double *blk, const OcLane &ln) { return d4{blk[ln.t4[0]], blk[ln.t4[1]], blk[ln.t4[2]], blk[ln.t4[3]]}; }
 __device__ __forceinline__ d4 oc_ldB4(const double *vec, int p, const OcLane &ln) { const double *q = vec + BS * p + ln.k4; return d4{q[0], q[4], q[8], q[12]}; }
 __device__ __forceinline__ void oc_stB4(double *vec, int p, const OcLane &ln, const double v) { vec[BS * p + ln.o4] = v; }      // (the four lanes of a quad store the same value)
+// A result of oc_mv4 as the operand pieces of the next product: piece K of lane (k, block, j) is the result element 4 K + k, which sits in the
+// lanes (k, block = K, j) -- quad K of every row of 16 lanes broadcast over the row: ds_swizzle in bit mode, lane' = (lane & 0x13) | (K << 2)
+// (no LDS memory access, no register hand-over through a store and a load)
+template <int K>
+__device__ __forceinline__ double oc_bc4k(const double v) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_ds_swizzle(a.i[0], (K << 7) | 0x13); r.i[1] = __builtin_amdgcn_ds_swizzle(a.i[1], (K << 7) | 0x13);
+  return r.d;
+}
+__device__ __forceinline__ d4 oc_bc4(const double v) { return d4{oc_bc4k<0>(v), oc_bc4k<1>(v), oc_bc4k<2>(v), oc_bc4k<3>(v)}; }
+__device__ __forceinline__ double oc_mv4x4(const d4 a, const d4 v, double acc) {
+  acc = oc_mv4(a[0], v[0], acc); acc = oc_mv4(a[1], v[1], acc); acc = oc_mv4(a[2], v[2], acc); acc = oc_mv4(a[3], v[3], acc);
+  return acc;
+}
+__device__ __forceinline__ double oc_ldE4(const double *vec, int p, const OcLane &ln) { return vec[BS * p + ln.o4]; }      // this lane's element of a vector block (the accumulator a product starts from)
 __device__ __forceinline__ int oc_tab(const int *tab, int k) { return __builtin_amdgcn_readfirstlane(tab[k]); }
 
 // After a factorisation (or on a kept workspace): bring the factor from the slab on chip.  Off-diagonal blocks are stored
@@ -379,8 +395,9 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     const int nst = len - 1;                           // stages: stage k multiplies block e[k].y into position e[k + 1].x
     // (table reads past the end are clamped to the last entry: the trip body has no branch, which keeps the compiler's wait counts exact)
     int2 e0 = oc_pair(tab, cb), e1 = oc_pair(tab, cb + 2 * min(1, nst)), e2 = oc_pair(tab, cb + 2 * min(2, nst)), e3 = oc_pair(tab, cb + 2 * min(3, nst));
-    d4 x = oc_ldB(R, e0.x, ln), y = x;
-    d4 a = oc_ldF(BL + (long)e0.y * BLK, ln), c = oc_ldB(R, e1.x, ln);
+    // (4-block MFMA: a stage is 4 dependent steps of 52 cycles, its result element goes to LDS and -- as the next stage's operand -- through ds_swizzle)
+    d4 x = oc_ldB4(R, e0.x, ln), y = x;
+    d4 a = oc_ldF4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e1.x, ln);
     int k = 0;
 #pragma unroll
     for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
@@ -389,26 +406,28 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
         while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
-      // stage k: y = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
-      const d4 a1 = oc_ldF(BL + (long)e1.y * BLK, ln), c1 = oc_ldB(R, e2.x, ln);
+      // stage k: t = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
+      const d4 a1 = oc_ldF4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e2.x, ln);
       const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
       __builtin_amdgcn_sched_barrier(0);               // the loads above are issued before the multiplies below: a whole stage to land
-      y = oc_mv(a, x, c);
-      oc_stB(R, e1.x, ln, y);
-      // stage k + 1: x = c1 + block(e1.y) y -> position e2.x ; prefetch stage k + 2: block e2.y, rhs of e3.x
-      a = oc_ldF(BL + (long)e2.y * BLK, ln); c = oc_ldB(R, e3.x, ln);
+      const double r0 = oc_mv4x4(a, x, c);
+      oc_stB4(R, e1.x, ln, r0);
+      y = oc_bc4(r0);
+      // stage k + 1: t = c1 + block(e1.y) y -> position e2.x ; prefetch stage k + 2: block e2.y, rhs of e3.x
+      a = oc_ldF4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e3.x, ln);
       __builtin_amdgcn_sched_barrier(0);
-      x = oc_mv(a1, y, c1);
-      oc_stB(R, e2.x, ln, x);
+      const double r1 = oc_mv4x4(a1, y, c1);
+      oc_stB4(R, e2.x, ln, r1);
+      x = oc_bc4(r1);
       e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
     }
-    if (k < nst) {                                     // odd stage count: one more, result in y
-      y = oc_mv(a, x, c);
-      oc_stB(R, e1.x, ln, y);
-      x = y; e0 = e1;
+    if (k < nst) {                                     // odd stage count: one more
+      const double r0 = oc_mv4x4(a, x, c);
+      oc_stB4(R, e1.x, ln, r0);
+      x = oc_bc4(r0); e0 = e1;
     }
     // x = t of the chain's last position e0.x
-    if (wid == 0 && oc.junc) oc_stB(EXT, 0, ln, oc_mv(oc_ldF(BL + (long)e0.y * BLK, ln), x, d4{0, 0, 0, 0}));
+    if (wid == 0 && oc.junc) oc_stB4(EXT, 0, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
   } else if (wid >= 2) {
     late(wid);
     if (wid == 3 && oc.at_poll >= 0) {
@@ -511,27 +530,29 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;
     d4 x;
-    if (wid == 0 && oc.junc) { x = oc_ldB(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
-    else x = oc_ldB(R, tab[cb + 2 * (len - 1)], ln);
+    if (wid == 0 && oc.junc) { x = oc_ldB4(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
+    else x = oc_ldB4(R, tab[cb + 2 * (len - 1)], ln);
     if (k >= 0) {
       int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
       d4 y = x;
-      d4 a = oc_ldT(BL + (long)e0.y * BLK, ln), c = oc_ldB(R, e0.x, ln);
+      d4 a = oc_ldT4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e0.x, ln);
 #pragma unroll
       for (int trip = 0; trip < OC_MAXT; trip++) {
         if (k < 1) break;
-        const d4 a1 = oc_ldT(BL + (long)e1.y * BLK, ln), c1 = oc_ldB(R, e1.x, ln);
+        const d4 a1 = oc_ldT4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e1.x, ln);
         const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
         __builtin_amdgcn_sched_barrier(0);
-        y = oc_mv(a, x, c);
-        oc_stB(R, e0.x, ln, y);
-        a = oc_ldT(BL + (long)e2.y * BLK, ln); c = oc_ldB(R, e2.x, ln);
+        const double r0 = oc_mv4x4(a, x, c);
+        oc_stB4(R, e0.x, ln, r0);
+        y = oc_bc4(r0);
+        a = oc_ldT4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e2.x, ln);
         __builtin_amdgcn_sched_barrier(0);
-        x = oc_mv(a1, y, c1);
-        oc_stB(R, e1.x, ln, x);
+        const double r1 = oc_mv4x4(a1, y, c1);
+        oc_stB4(R, e1.x, ln, r1);
+        x = oc_bc4(r1);
         e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
       }
-      if (k == 0) oc_stB(R, e0.x, ln, oc_mv(a, x, c));
+      if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
     }
   } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();

@@ -614,23 +614,27 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   };
   auto barrier = [&]() { std::fill(wr.begin(), wr.end(), -1); std::fill(rd.begin(), rd.end(), 0); };
   const int ext0 = pl.npad / BS;
-  // F1
+  // F1 (4-block MFMA: the result element of a stage goes to LDS and, through the quad broadcast of ds_swizzle, into the next stage's operand)
+  auto bc4 = [](const Wave1 &r) { Wave x; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) x.v[l][K] = r.v[(l & 0x33) | (K << 2)]; return x; };
+  auto ldE4 = [](const double *vec, int p) { Wave1 r; for (int l = 0; l < 64; l++) r.v[l] = vec[BS * p + 4 * ((l >> 2) & 3) + (l >> 4)]; return r; };
+  bool quads1 = true;
   for (int w = 0; w < 2; w++) {
     const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
     if (len == 0) continue;
     int e = 0; touch(w, tab[cb], false);
-    Wave x = ldB(R.data(), tab[cb]);
+    Wave x = ldB4(R.data(), tab[cb]);
     for (int k = 0; k + 1 < len; k++) {
       const int slot = tab[cb + 2 * k + 1], pn = tab[cb + 2 * (k + 1)];
       touch(w, pn, false);
-      Wave c = ldB(R.data(), pn);
-      mv(ldF(&BL[(size_t)slot * BLK]), x, c);
+      Wave1 c = ldE4(R.data(), pn);
+      mv4(ldF4(&BL[(size_t)slot * BLK]), x, c);
       touch(w, pn, true);
-      if (!stB(R.data(), pn, c)) return 1;
-      x = c; e = k + 1;
+      quads1 = stB4(R.data(), pn, c) && quads1;
+      x = bc4(c); e = k + 1;
     }
-    if (w == 0 && oc.junc) { Wave c = zero(); mv(ldF(&BL[(size_t)tab[cb + 2 * e + 1] * BLK]), x, c); touch(w, ext0, true); if (!stB(EXT, 0, c)) return 1; }
+    if (w == 0 && oc.junc) { Wave1 c = zero1(); mv4(ldF4(&BL[(size_t)tab[cb + 2 * e + 1] * BLK]), x, c); touch(w, ext0, true); quads1 = stB4(EXT, 0, c) && quads1; }
   }
+  if (!quads1) return 1;
   barrier();
   if (f >= 0) { const int w = f & (nw - 1); touch(w, f, false); touch(w, ext0, false); Wave t = add(ldB(R.data(), f), ldB(EXT, 0)); touch(w, f, true); stB(R.data(), f, t); }
   std::vector<Wave> xh(nw, zero());
@@ -674,14 +678,14 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
     const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
     if (len == 0) continue;
     int k = len - 2; Wave x;
-    if (w == 0 && oc.junc) { touch(w, f, false); x = ldB(R.data(), f); k = len - 1; } else { touch(w, tab[cb + 2 * (len - 1)], false); x = ldB(R.data(), tab[cb + 2 * (len - 1)]); }
+    if (w == 0 && oc.junc) { touch(w, f, false); x = ldB4(R.data(), f); k = len - 1; } else { touch(w, tab[cb + 2 * (len - 1)], false); x = ldB4(R.data(), tab[cb + 2 * (len - 1)]); }
     for (; k >= 0; k--) {
       const int p = tab[cb + 2 * k], slot = tab[cb + 2 * k + 1];
       touch(w, p, false);
-      Wave c = ldB(R.data(), p);
-      mv(ldT(&BL[(size_t)slot * BLK]), x, c);
-      touch(w, p, true); stB(R.data(), p, c);
-      x = c;
+      Wave1 c = ldE4(R.data(), p);
+      mv4(ldT4(&BL[(size_t)slot * BLK]), x, c);
+      touch(w, p, true); if (!stB4(R.data(), p, c)) return 1;
+      x = bc4(c);
     }
   }
   if (hazard) return 3;
