@@ -44,12 +44,13 @@ __host__ __device__ __forceinline__ int oc_phi(int m) { return 4 * (m & 3) + (m 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 struct OcLane {
-  int fLo, fHi;      // doubles inside a swizzled LDS block: elements (phi(n), 4 kk + 0..1) and (phi(n), 4 kk + 2..3)
+  int fLo, fHi;      // doubles inside a swizzled LDS block: elements (phi(n), 4 kk + 0..1) and (phi(n), 4 kk + 2..3)   (16x16x4 layout: the factorisation's hand-overs)
   int t0, t1, t2, t3;   // elements (4 kk + i, phi(n))
   int vb;            // 4 kk: this lane group's piece of a vector block
-  // the 4-block MFMA of the hub / diagonal phases (oc_mv4 below): row r4 = lane & 15, k4 = lane >> 4
-  int f4[4];         // elements (r4, k4 + 4 K) of a swizzled LDS block, K = 0..3
-  int t4[4];         // elements (k4 + 4 K, r4)
+  // the 4-block MFMA of the solve (oc_mv4 below): row r4 = lane & 15, k4 = lane >> 4.  The eight block offsets are bytes of two registers:
+  // every register the solve keeps live across the iteration counts (a spilled offset is a scratch reload with a full wait in front of a chain)
+  unsigned f4;       // byte K: element (r4, k4 + 4 K) of a swizzled LDS block
+  unsigned t4;       // byte K: element (k4 + 4 K, r4)
   int k4;            // this lane's piece of a vector: v[k4 + 4 K]
   int o4;            // the element of the result this lane holds: 4 ((lane >> 2) & 3) + (lane >> 4)
   bool col0;         // n == 0 (lane & 15 == 0)
@@ -60,8 +61,9 @@ __device__ __forceinline__ OcLane oc_lane(int lane) {
   ln.fLo = oc_swz(r, 4 * kk); ln.fHi = oc_swz(r, 4 * kk + 2);
   ln.t0 = oc_swz(4 * kk, r); ln.t1 = oc_swz(4 * kk + 1, r); ln.t2 = oc_swz(4 * kk + 2, r); ln.t3 = oc_swz(4 * kk + 3, r);
   ln.vb = 4 * kk; ln.col0 = n == 0;
+  ln.f4 = 0; ln.t4 = 0;
 #pragma unroll
-  for (int K = 0; K < 4; K++) { ln.f4[K] = oc_swz(n, kk + 4 * K); ln.t4[K] = oc_swz(kk + 4 * K, n); }
+  for (int K = 0; K < 4; K++) { ln.f4 |= (unsigned)oc_swz(n, kk + 4 * K) << (8 * K); ln.t4 |= (unsigned)oc_swz(kk + 4 * K, n) << (8 * K); }
   ln.k4 = kk; ln.o4 = 4 * ((lane >> 2) & 3) + (lane >> 4);
   return ln;
 }
@@ -89,8 +91,9 @@ __device__ __forceinline__ d4 oc_mv(const d4 a, const d4 v, d4 acc) {
 // step K takes the tile W[4 b .. + 3][4 K .. + 3] and the piece v[4 K .. + 3] in every column: lane l supplies W[l & 15][(l >> 4) + 4 K] and
 // v[(l >> 4) + 4 K], and receives out[4 ((l >> 2) & 3) + (l >> 4)].  Several such products run interleaved (oc_mv4 is one step of one of them).
 __device__ __forceinline__ double oc_mv4(const double a, const double v, const double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, v, acc, 0, 0, 0); }
-__device__ __forceinline__ d4 oc_ldF4(const double *blk, const OcLane &ln) { return d4{blk[ln.f4[0]], blk[ln.f4[1]], blk[ln.f4[2]], blk[ln.f4[3]]}; }
-__device__ __forceinline__ d4 oc_ldT4(const double *blk, const OcLane &ln) { return d4{blk[ln.t4[0]], blk[ln.t4[1]], blk[ln.t4[2]], blk[ln.t4[3]]}; }
+__device__ __forceinline__ d4 oc_ld4(const double *blk, const unsigned pk) { return d4{blk[pk & 255], blk[(pk >> 8) & 255], blk[(pk >> 16) & 255], blk[pk >> 24]}; }
+__device__ __forceinline__ d4 oc_ldF4(const double *blk, const OcLane &ln) { return oc_ld4(blk, ln.f4); }
+__device__ __forceinline__ d4 oc_ldT4(const double *blk, const OcLane &ln) { return oc_ld4(blk, ln.t4); }
 __device__ __forceinline__ d4 oc_ldB4(const double *vec, int p, const OcLane &ln) { const double *q = vec + BS * p + ln.k4; return d4{q[0], q[4], q[8], q[12]}; }
 __device__ __forceinline__ void oc_stB4(double *vec, int p, const OcLane &ln, const double v) { vec[BS * p + ln.o4] = v; }      // (the four lanes of a quad store the same value)
 // A result of oc_mv4 as the operand pieces of the next product: piece K of lane (k, block, j) is the result element 4 K + k, which sits in the
@@ -380,7 +383,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
 #define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #else
-#define OC_TS(k)
+#define OC_TS(k) __builtin_amdgcn_sched_barrier(0)
 #endif
   double *EXT = R + npad;                          // vector blocks behind the solve vector
   const int LE = oc_tab(tab, 0), LF = oc_tab(tab, 1);
@@ -432,12 +435,12 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     late(wid);
     if (wid == 3 && oc.at_poll >= 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (ln.col0 && ln.vb == 0) *ticket = iter;
+      if (ln.o4 == 0) *ticket = iter;
     }
   }
   bsync<NW>();
   OC_TS(0);
-  if (f >= 0 && wid == (f & (NW - 1))) oc_stB(R, f, ln, oc_ldB(R, f, ln) + oc_ldB(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
+  if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
   d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand pieces (k4 + 4 K)
   double xhd = 0.0;           // ... and as its element of the result (o4)
   constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
