@@ -254,23 +254,25 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
       else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
       else {
-        // LDS-resident 4-wave kernel while two fit a CU.  (Against it the two-wave global-block kernel below is +8...11 % on double integrator
-        // N=40 / 50 and +3 % on cart-pole N=30, but -6 % on cart-pole N=25 and -3 % on quadrotor N=7: no clean rule, so the resident kernel stays)
-        if (small_ok && l4 <= 80 * 1024) want = 4;
+        // The on-chip mode (factor in LDS + registers at two workgroups per CU, solves and factorisation on the matrix cores) wherever the pattern is
+        // a block chain with an arrow head that fits it AND the alternative is the LDS-resident 4-wave kernel at two workgroups per CU or a factor
+        // streamed from the slab (measured, profiles/r02_final_variant_grid.txt, x 8192: quadrotor N = 6 ... 20 +8 ... +48 %, cart-pole N = 30 / 40 / 50
+        // +20 / +26 / +37 %, double integrator N = 40 ... 80 +12 ... +64 %).  With three or more resident workgroups per CU the LDS-resident
+        // kernels stay ahead (quadrotor N = 5 2.57 vs 2.06 M QP/s, cart-pole N = 20 818k vs 656k, double integrator N = 30 792k vs 611k).
+        auto oc_takes = [&]() {
+          if (getenv("MPCQP_NO_OC") || !small_ok) return false;
+          const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
+          return o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX;
+        };
+        // LDS-resident 4-wave kernel while two fit a CU
+        if (small_ok && l4 <= 80 * 1024) { want = 4; if (l4 > 53 * 1024 && oc_takes()) { h->gblocks = true; h->oc = true; } }
         // factor streamed from the slab, two waves per QP (168-VGPR instance, six workgroups per CU) while six fit the LDS: ahead of four waves x
-        // four workgroups there (double integrator N=100 145k -> 156k QP/s, cart-pole N=50 234k -> 256k, quadrotor N=10 1.11 -> 1.19 M; at 32 KiB
-        // and above four waves win)
+        // four workgroups there (double integrator N=100 145k -> 156k QP/s; at 32 KiB and above four waves win)
         else if (small_ok && !getenv("MPCQP_NO_RES2") && lds_bytes_res_gb(p4, build_res_plan(p4, 2, true)) <= LDS_MAX / 6) {
           want = 2; h->gblocks = true;
-          // ... unless the on-chip mode takes the pattern and the two sweeps over A and A' are the heavy part of an iteration (slots per chain
-          // block; measured, profiles/r02_final_variant_grid.txt: 12-state quadrotor N = 10 / 12 / 15 at 8.5 - 7.9 slots per block +11 / +12 / +20 %
-          // over the two-wave kernel; cart-pole N = 40 / 50 at 5.1 and double integrator N = 60 at 2.7: -9 / -4 / -13 %)
-          if (!getenv("MPCQP_NO_OC")) {
-            const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
-            if (o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX && 2L * (p4.A.slots() + p4.At.slots()) >= 13L * o.nbc) { want = 4; h->oc = true; }
-          }
+          if (oc_takes()) { want = 4; h->oc = true; }
         }
-        else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; h->oc = !getenv("MPCQP_NO_OC"); }
+        else if (small_ok && lds_bytes_res_gb(p4, build_res_plan(p4, 4, true), !getenv("MPCQP_NO_ZYG")) <= LDS_MAX) { want = 4; h->gblocks = true; h->oc = oc_takes(); }
         else want = 0;
       }
     }

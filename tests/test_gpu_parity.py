@@ -364,14 +364,13 @@ def test_onchip_is_the_default_for_the_north_star_size(built):
     mdl, ls, _ = models.make_workload("quadrotor", 2, N=20)
     qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
     assert info["variant"] == 204 and info["lds_bytes"] <= 80 * 1024
-    # ... and where the two-wave global-block kernel used to be taken and the sweeps over A, A' are heavy (mpcqp.hip selection rule);
-    # not for the small-block models at that size
-    mdl, ls, _ = models.make_workload("quadrotor", 2, N=10)
-    qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
-    assert info["variant"] == 204
-    mdl, ls, _ = models.make_workload("cartpole", 2, N=40)
-    qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
-    assert info["variant"] == 102
+    # ... and wherever the alternative is a factor streamed from the slab or the LDS-resident kernel at two workgroups per CU (mpcqp.hip
+    # selection rule); with three or more resident workgroups per CU the LDS-resident kernels stay
+    for name, N, want in (("quadrotor", 10, 204), ("cartpole", 40, 204), ("double_integrator", 60, 204), ("quadrotor", 7, 204),
+                          ("quadrotor", 5, 4), ("cartpole", 20, 4), ("double_integrator", 20, 2)):
+        mdl, ls, _ = models.make_workload(name, 2, N=N)
+        qp = BatchQP(ls.n, ls.m, 8192, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+        assert info["variant"] == want, (name, N, info["variant"])
 
 
 @pytest.mark.parametrize("knob", ["MPCQP_NO_LATE", "MPCQP_NO_REMAP", "MPCQP_NO_TOUCH", "MPCQP_OC_PAD4"])
