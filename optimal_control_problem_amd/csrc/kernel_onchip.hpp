@@ -414,14 +414,16 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
       const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
       __builtin_amdgcn_sched_barrier(0);               // the loads above are issued before the multiplies below: a whole stage to land
       const double r0 = oc_mv4x4(a, x, c);
+      y = oc_bc4(r0);                                  // (the hand-over first: the LDS pipe is in order, and the next stage waits for exactly this)
+      __builtin_amdgcn_sched_barrier(0);
       oc_stB4(R, e1.x, ln, r0);
-      y = oc_bc4(r0);
       // stage k + 1: t = c1 + block(e1.y) y -> position e2.x ; prefetch stage k + 2: block e2.y, rhs of e3.x
       a = oc_ldF4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e3.x, ln);
       __builtin_amdgcn_sched_barrier(0);
       const double r1 = oc_mv4x4(a1, y, c1);
-      oc_stB4(R, e2.x, ln, r1);
       x = oc_bc4(r1);
+      __builtin_amdgcn_sched_barrier(0);
+      oc_stB4(R, e2.x, ln, r1);
       e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
     }
     if (k < nst) {                                     // odd stage count: one more
@@ -546,13 +548,15 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
         const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
         __builtin_amdgcn_sched_barrier(0);
         const double r0 = oc_mv4x4(a, x, c);
-        oc_stB4(R, e0.x, ln, r0);
         y = oc_bc4(r0);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stB4(R, e0.x, ln, r0);
         a = oc_ldT4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e2.x, ln);
         __builtin_amdgcn_sched_barrier(0);
         const double r1 = oc_mv4x4(a1, y, c1);
-        oc_stB4(R, e1.x, ln, r1);
         x = oc_bc4(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stB4(R, e1.x, ln, r1);
         e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
       }
       if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
