@@ -221,6 +221,10 @@ struct StageModel { int builtin = -1; std::string library; double par[8] = {0};
   static StageModel fromLibrary(const std::string &path) { StageModel m; m.library = path; return m; } };
 struct Dynamics { StageModel model; Var state, input; int size() const { return state.size(); } };   // F(state_k, input_k)
 struct Path { StageModel model; Var state, input; int rows = 0; int size() const { return rows; } };  // h(state_k, input_k)
+// k(state_k, input_k, state_{k+1}, input_{k+1}) of two consecutive frames (a rate limit u_{k+1} - u_k, a slew limit on a state), carried by the
+// generated library of the dynamics (codegen.trace(F, ..., kfun=, nk=, k_lo=, k_hi=)): the stand-in for an SX expression over several
+// frames (src/OptimalControlProblem.cpp:448-489); ocp.py's Link
+struct Link { StageModel model; Var state, input, stateNext, inputNext; int rows = 0; int size() const { return rows; } };
 struct Cost { int kind = 0; Var var; bool minusReference = false; std::vector<double> weight; };       // sum_i w_i e_i^2
 // general cost term l(state_k, input_k, reference) of one frame, carried by the generated library of the dynamics (codegen.trace with
 // lcost / lterm): the stand-in for an arbitrary SX term of the reference (src/OptimalControlProblem.cpp:491-497)
@@ -283,7 +287,7 @@ class OptimalControlProblem {
  public:
   enum class SolverType { IPOPT, SQP, CUDA_SQP, MIXED };
   using Var = ocp_expr::Var; using Reference = ocp_expr::Reference; using Diff = ocp_expr::Diff;
-  using Dynamics = ocp_expr::Dynamics; using Path = ocp_expr::Path; using StageModel = ocp_expr::StageModel; using StageCost = ocp_expr::StageCost;
+  using Dynamics = ocp_expr::Dynamics; using Path = ocp_expr::Path; using StageModel = ocp_expr::StageModel; using StageCost = ocp_expr::StageCost; using Link = ocp_expr::Link;
 
   std::unique_ptr<OCPConfig> OCPConfigPtr_;
   Reference reference_;
@@ -329,7 +333,13 @@ class OptimalControlProblem {
       throw std::invalid_argument("SX used for inequality constraints has different dimensions!");    // :452-454
     paths_.push_back({expression, lowerBound, upperBound}); constraintNames_.insert(constraintNames_.end(), expression.size(), constraintName);
   }
-  size_t getConstraints() const { return dynamics_.size() + paths_.size(); }
+  void addInequalityConstraint(const std::string &constraintName, const std::vector<double> &lowerBound, const Link &expression,
+                               const std::vector<double> &upperBound) {
+    if ((int)lowerBound.size() != expression.size() || (int)upperBound.size() != expression.size())
+      throw std::invalid_argument("SX used for inequality constraints has different dimensions!");    // :452-454
+    links_.push_back({expression, lowerBound, upperBound}); constraintNames_.insert(constraintNames_.end(), expression.size(), constraintName);
+  }
+  size_t getConstraints() const { return dynamics_.size() + paths_.size() + links_.size(); }
   size_t getCostFunction() const { return costs_.size() + stageCosts_.size(); }
 
   // genSolver (:224-442), CUDA_SQP arm :391-401
@@ -340,8 +350,8 @@ class OptimalControlProblem {
     if (solverType_ != SolverType::CUDA_SQP)
       throw std::runtime_error("this solve_method relies on third-party NLP solvers (IPOPT / qpOASES) and is out of scope; use CUDA_SQP");
     const int N = cfg.getHorizon(), f = cfg.getFrameSize();
-    if ((int)dynamics_.size() != N - 1 || !(paths_.empty() || (int)paths_.size() == N))
-      throw std::runtime_error("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames and one per-frame path constraint");
+    if ((int)dynamics_.size() != N - 1 || !(paths_.empty() || (int)paths_.size() == N) || !(links_.empty() || (int)links_.size() == N - 1))
+      throw std::runtime_error("this facade compiles dynamics defects x_{k+1} - F(x_k, u_k) between consecutive frames, one per-frame path constraint and one link constraint per pair of consecutive frames");
     const Var s0 = dynamics_[0].second.state, u0 = dynamics_[0].second.input;
     const int nx = s0.size(), nu = u0.size();
     if (s0.offset != 0 || u0.offset != nx || nx + nu != f) throw std::runtime_error("frame layout must be [state; input]");
@@ -384,7 +394,19 @@ class OptimalControlProblem {
     solver_.reset(new StageSQP(d, batch_, stepNum_, alpha_, mdl.builtin >= 0 ? nullptr : mdl.library.c_str()));
     if (solver_->nx() != nx || solver_->nu() != nu) throw std::runtime_error("the compiled model's state / input sizes differ from the YAML frame");
     nh_ = paths_.empty() ? 0 : paths_[0].expr.size();
-    if (solver_->ng() != (N - 1) * nx + N * nh_) throw std::runtime_error("the compiled model's path constraint differs from the one added");
+    nk_ = links_.empty() ? 0 : links_[0].expr.size();
+    if (nk_ > 0) {
+      std::vector<char> got(N, 0);
+      for (auto &l : links_) {
+        const int k = l.expr.state.step;
+        if (k < 0 || k >= N - 1 || got[k] || l.expr.input.step != k || l.expr.stateNext.step != k + 1 || l.expr.inputNext.step != k + 1 ||
+            l.expr.size() != nk_ || l.expr.model.library != mdl.library || mdl.builtin >= 0)
+          throw std::runtime_error("a Link takes the state and input of frames k and k + 1 and lives in the library of the dynamics");
+        got[k] = 1;
+      }
+    }
+    // rows of the constraint vector: dynamics defects, path rows, link rows (csrc/stage_kernels.hpp)
+    if (solver_->ng() != (N - 1) * nx + N * nh_ + (N - 1) * nk_) throw std::runtime_error("the compiled model's path / link constraints differ from the ones added");
     if (nh_ > 0) {   // bounds may differ by frame (a terminal constraint is loose on every frame but the last): tell the violation measure
       std::vector<double> lo((size_t)N * nh_), hi((size_t)N * nh_);
       for (auto &p : paths_) for (int r = 0; r < nh_; r++) { lo[(size_t)p.expr.state.step * nh_ + r] = p.lo[r]; hi[(size_t)p.expr.state.step * nh_ + r] = p.hi[r]; }
@@ -417,8 +439,14 @@ class OptimalControlProblem {
           arg.lbx[at] = k == 0 ? frame[(size_t)b * fs + i] : cfg.getLowerBounds()[k][i];               // :95-96 the whole first frame is pinned
           arg.ubx[at] = k == 0 ? frame[(size_t)b * fs + i] : cfg.getUpperBounds()[k][i];
         }
-    const int ngd = (N - 1) * nx_, ng = ngd + N * nh_;
+    const int ngd = (N - 1) * nx_, ngh = ngd + N * nh_, ng = ngh + (N - 1) * nk_;
     arg.lbg.assign((size_t)batch_ * ng, 0.0); arg.ubg.assign((size_t)batch_ * ng, 0.0);                 // dynamics rows: [0, 0]
+    for (auto &l : links_)
+      for (int b = 0; b < batch_; b++)
+        for (int r = 0; r < nk_; r++) {
+          arg.lbg[(size_t)b * ng + ngh + (size_t)l.expr.state.step * nk_ + r] = l.lo[r];
+          arg.ubg[(size_t)b * ng + ngh + (size_t)l.expr.state.step * nk_ + r] = l.hi[r];
+        }
     for (auto &p : paths_)
       for (int b = 0; b < batch_; b++)
         for (int r = 0; r < nh_; r++) {
@@ -441,7 +469,9 @@ class OptimalControlProblem {
     return s["SQP_settings"]["alpha"].IsDefined() && s["SQP_settings"]["step_num"].IsDefined();
   }
   struct PathRow { Path expr; std::vector<double> lo, hi; };
-  int batch_ = 1, maxIter_ = 1000, stepNum_ = 10, nx_ = 0, nu_ = 0, nh_ = 0;
+  struct LinkRow { Link expr; std::vector<double> lo, hi; };
+  std::vector<LinkRow> links_;
+  int batch_ = 1, maxIter_ = 1000, stepNum_ = 10, nx_ = 0, nu_ = 0, nh_ = 0, nk_ = 0;
   double alpha_ = 0.1; bool warmStart_ = true, verbose_ = true, genCode_ = false, loadLib_ = false, firstTime_ = true;
   SolverType solverType_ = SolverType::CUDA_SQP;
   std::vector<std::pair<Var, Dynamics>> dynamics_; std::vector<PathRow> paths_; std::vector<ocp_expr::Cost> costs_; std::vector<StageCost> stageCosts_;

@@ -152,10 +152,55 @@ static int test_cost(const char *lib) {
   return 0;
 }
 
+// link constraint between consecutive frames (a rate limit on the input) from a generated library (argv[2], made by
+// codegen.trace(F, ..., kfun=, nk=, k_lo=, k_hi=)): prints the trajectories for the caller to compare with the Python facade
+class RateLimitOCP : public OptimalControlProblem {
+ public:
+  RateLimitOCP(const YamlNode &n, int batch, const std::string &lib) : OptimalControlProblem(n, batch), lib_(lib) {}
+  void deployConstraintsAndAddCost() override {
+    const OCPConfig &cfg = *OCPConfigPtr_;
+    const int N = cfg.getHorizon();
+    Reference ref = setReference(2);
+    const StageModel plant = StageModel::fromLibrary(lib_);
+    for (int k = 0; k < N; k++) { addVectorCost({10.0, 1.0}, cfg.getVariable(k, "state") - ref); addVectorCost({0.1}, cfg.getVariable(k, "input")); }
+    for (int k = 0; k < N - 1; k++) {
+      addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics{plant, cfg.getVariable(k, "state"), cfg.getVariable(k, "input")});
+      if (links_on_) addInequalityConstraint("rate", {-0.15}, Link{plant, cfg.getVariable(k, "state"), cfg.getVariable(k, "input"),
+                                                                   cfg.getVariable(k + 1, "state"), cfg.getVariable(k + 1, "input"), 1}, {0.15});
+    }
+  }
+  std::string lib_;
+  bool links_on_ = true;
+};
+
+static int test_link(const char *lib) {
+  const int B = 6;
+  RateLimitOCP ocp(YamlNode::Load(kYaml)["optimal_control_problem"], B, lib);
+  ocp.deployConstraintsAndAddCost();
+  EXPECT(ocp.getConstraints() == 19 + 19);
+  ocp.genSolver();
+  std::vector<double> frame((size_t)B * 3), ref((size_t)B * 2, 0.0);
+  for (int b = 0; b < B; b++) { frame[b * 3] = -1.5 + 0.6 * b; frame[b * 3 + 1] = 0.4 - 0.15 * b; frame[b * 3 + 2] = 0.0; }
+  const std::vector<double> &traj = ocp.computeOptimalTrajectory(frame, ref);
+  EXPECT((int)traj.size() == B * 60);
+  for (int b = 0; b < B; b++) {
+    for (int k = 0; k + 1 < 20; k++) EXPECT(std::fabs(traj[(size_t)b * 60 + (k + 1) * 3 + 2] - traj[(size_t)b * 60 + k * 3 + 2]) <= 0.15 + 5e-3);   // the limit holds
+    std::printf("traj"); for (int i = 0; i < 60; i++) std::printf(" %.17g", traj[(size_t)b * 60 + i]); std::printf("\n");
+  }
+  // the library carries a link constraint: leaving the Link terms out is refused (the row counts differ)
+  RateLimitOCP without(YamlNode::Load(kYaml)["optimal_control_problem"], B, lib);
+  without.links_on_ = false;
+  without.deployConstraintsAndAddCost();
+  EXPECT(throws<std::runtime_error>([&] { without.genSolver(); }));
+  std::printf("link ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   try {
     if (argc > 1 && std::strcmp(argv[1], "config") == 0) return test_config();
     if (argc > 2 && std::strcmp(argv[1], "cost") == 0) return test_cost(argv[2]);
+    if (argc > 2 && std::strcmp(argv[1], "link") == 0) return test_link(argv[2]);
     return test_run();
   } catch (const std::exception &e) { std::fprintf(stderr, "uncaught: %s\n", e.what()); return 1; }
 }

@@ -137,3 +137,45 @@ def test_cpp_ocp_general_cost_equals_python_facade(built):
     frame = np.array([[-0.8 + 0.5 * b, 0.2, 0.0] for b in range(B)]); ref = np.array([[0.1 * b, 0.0] for b in range(B)])
     want = ocp.computeOptimalTrajectory(frame, ref)
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9 * (1 + np.abs(want).max())
+
+
+def _di_rate(s, u, sn, un):
+    return np.stack([un[..., 0] - u[..., 0]], axis=-1)
+
+
+@pytest.mark.gpu
+def test_cpp_ocp_link_constraint_equals_python_facade(built):
+    """C++ OptimalControlProblem::addInequalityConstraint with a Link (rate limit between consecutive frames, carried by the generated
+    library) against the Python facade on the same problem, both device-resident: the form of SX expressions over several frames
+    (reference src/OptimalControlProblem.cpp:448-489) this facade takes"""
+    import yaml
+    from optimal_control_problem_amd import codegen
+    from optimal_control_problem_amd.ocp import Dynamics, Link, OptimalControlProblem
+    lib = codegen.build_device_library(codegen.trace(_di_step, 2, 1, kfun=_di_rate, nk=1, k_lo=[-0.15], k_hi=[0.15]))
+    r = subprocess.run([OCP_EXE, "link", lib], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "link ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    got = np.array([[float(v) for v in line.split()[1:]] for line in r.stdout.splitlines() if line.startswith("traj")])
+    text = """
+      discretization_settings: {dt: 0.05, horizon: 20}
+      solver_settings: {verbose: false, gen_code: true, load_lib: false, max_iter: 1000, warm_start: true, solve_method: CUDA_SQP,
+                        SQP_settings: {alpha: 1.0, step_num: 2}}
+      OCP_variables:
+        - {name: state, size: 2, lower_bound: [-.inf, -2.0], upper_bound: [.inf, 2.0]}
+        - {name: input, size: 1, lower_bound: [-1.0], upper_bound: [1.0]}
+    """
+
+    class DI(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            cfg = self.OCPConfigPtr_; ref = self.setReference(2); N = cfg.getHorizon()
+            for k in range(N):
+                st, inp = cfg.getVariable(k, "state"), cfg.getVariable(k, "input")
+                self.addVectorCost([10.0, 1.0], st - ref); self.addVectorCost([0.1], inp)
+                if k < N - 1:
+                    self.addEquationConstraint("dynamics", cfg.getVariable(k + 1, "state"), Dynamics(_di_step, st, inp))
+                    self.addInequalityConstraint("rate", [-0.15], Link(_di_rate, st, inp, cfg.getVariable(k + 1, "state"), cfg.getVariable(k + 1, "input"), 1), [0.15])
+
+    B = 6
+    ocp = DI(yaml.safe_load(text), batch=B); ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    frame = np.array([[-1.5 + 0.6 * b, 0.4 - 0.15 * b, 0.0] for b in range(B)]); ref = np.zeros((B, 2))
+    want = ocp.computeOptimalTrajectory(frame, ref)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9 * (1 + np.abs(want).max())
