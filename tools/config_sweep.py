@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The BASELINE.json configurations that fit one GPU (plus neighbours), one bench.py line each -> one JSON list.
-usage: python tools/config_sweep.py > profiles/r01_config_sweep.json   (GPU box)"""
+usage: python tools/config_sweep.py > profiles/rNN_config_sweep.json   (GPU box; `value` is in batch order from round 2 on)"""
 import json
 import os
 import subprocess
@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("double_integrator", 20, 4096, "BASELINE configs[1]"), ("quadrotor", 20, 8192, "north star"), ("quadrotor", 50, 8192, "BASELINE configs[2], one shard of configs[4]"),
          ("cartpole", 100, 16384, "BASELINE configs[3] (one QP of the SQP loop, cold start; the warm-started loop is profiles/r01_sqp_device_loop.json)"),
-         ("cartpole", 30, 8192, ""), ("quadrotor", 10, 8192, ""), ("quadrotor", 100, 2048, "")]
+         ("cartpole", 30, 8192, ""), ("cartpole", 50, 8192, ""), ("double_integrator", 60, 8192, ""), ("quadrotor", 10, 8192, ""), ("quadrotor", 100, 2048, "")]
 out = []
 for w, n, b, note in CASES:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--horizon", str(n), "--batch", str(b), "--no-cpu-baseline", "--no-extras",
