@@ -1,5 +1,5 @@
-// kernel_onchip.hpp -- the "on-chip" solve of mpcqp_res_kernel<..., OCG, OCH>: the whole block LDL' factor stays on the CU at two
-// workgroups per CU, and every 16x16 mat-vec of the triangular solves runs on the matrix cores, register to register along a chain
+// kernel_onchip.hpp -- the "on-chip" mode of mpcqp_res_kernel<..., OCG, OCH>: the whole block LDL' factor stays on the CU at two workgroups
+// per CU; the triangular solves, and the factorisation of this topology, run on the matrix cores
 // Part of the single translation unit mpcqp.hip (included there in order; not a stand-alone header).
 #pragma once
 
@@ -9,19 +9,12 @@
 // such QP per CU and is bound by the latency of its dependent chain ops (LDS write -> wave fence -> LDS read -> FMAs -> DPP
 // quad sum per stage, 330-550 cycles).  Here the factor is split over both on-chip memories so that TWO workgroups fit a CU:
 //   * chain blocks W_succ(p),p, the hub's inverse diagonal block and as many hub blocks W_hub,p as fit: LDS (<= 80 KB per
-//     workgroup), one swizzled copy that is read conflict-free in both orientations (forward sweep: rows, backward: columns);
+//     workgroup), one swizzled copy (oc_swz) that is read in both orientations (forward sweep: rows, backward: columns);
 //   * the inverse diagonal blocks G_p (symmetric: one orientation) and the remaining hub blocks (both orientations): registers
 //     of the wave that owns position p (p mod 4), statically indexed.
-// and a mat-vec is 4 x v_mfma_f64_16x16x4_f64 with the vector in column 0 of the B operand.  With the index map phi below the
-// C/D layout of column 0 IS the B layout of the next op, so a chain t_succ(p) = rhs - W t_p runs register to register: 4
-// dependent MFMAs per stage and no LDS round trip on the critical path.  (Only 1 of 16 MFMA columns carries data; the
-// matrix pipe has the room: 404 MFMAs per solve and QP = 13k pipe-cycles over 4 SIMDs.)
-//
-// MFMA index m (0..15) <-> position a inside a 16-block: a = phi(m) = 4 (m & 3) + (m >> 2).  Lane l = 16 kk + n:
-//   A operand  A[m = n][k = kk + 4 i], i = 0..3  ->  block[phi(n)][4 kk + i]   (a row piece: one 32-byte read)
-//   B operand  B[k = kk + 4 i][n]               ->  vec[4 kk + i]              (the same 32 bytes for the 16 lanes of a group)
-//   C/D        D[m = kk + 4 g][n], g = 0..3     ->  out[4 kk + g]              (every column n holds the same vector)
-// The transposed op y = W' v reads A[m = n][k] = block[4 kk + i][phi(n)] (four 8-byte reads down a column).
+// A 16x16 mat-vec of the solve is four steps of v_mfma_f64_4x4x4_4b_f64 (oc_mv4 below: layout, cost and how a result becomes
+// the next operand); the products of the factorisation (oc_ldl: 16x16 times 16x16, all sixteen columns in use) are four
+// v_mfma_f64_16x16x4_f64 each, with the operand layouts D(X) / A(X) described there.
 // =========================================================================================================
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
@@ -32,51 +25,34 @@ struct DevOc {
   const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
 };
 
-// LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart
-// (transposed reads touch rows i, 4 + i, 8 + i, 12 + i at once), the four 32-byte pieces of a row are rotated by the row pair,
-// and the two 16-byte halves of a piece are swapped in the lower eight rows: a row-piece read (ds_read_b128 x 2) of 16 lanes
-// covers all 64 banks once, a column read (ds_read_b64) of 32 lanes as well.
+// LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart, the four
+// 32-byte pieces of a row are rotated by the row pair, and the two 16-byte halves of a piece are swapped in the lower eight rows.  The
+// solve reads a block element by element -- sixteen rows x one 32-byte piece per step (forward), four rows x sixteen columns (backward):
+// at most two lanes per bank either way.
 __host__ __device__ __forceinline__ int oc_swz(int r, int c) {
   return ((r ^ ((r >> 2) & 1)) << 4) | (c ^ (((r >> 1) & 3) << 2) ^ (((r >> 3) & 1) << 1));
 }
-__host__ __device__ __forceinline__ int oc_phi(int m) { return 4 * (m & 3) + (m >> 2); }
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// what a lane of the solve keeps about itself (oc_mv4 below): row r4 = lane & 15, k4 = lane >> 4.  The eight block offsets are bytes of two
+// registers: every register the solve keeps live across the iteration counts (a spilled offset is a scratch reload with a full wait in front of a chain)
 struct OcLane {
-  int fLo, fHi;      // doubles inside a swizzled LDS block: elements (phi(n), 4 kk + 0..1) and (phi(n), 4 kk + 2..3)   (16x16x4 layout: the factorisation's hand-overs)
-  int t0, t1, t2, t3;   // elements (4 kk + i, phi(n))
-  int vb;            // 4 kk: this lane group's piece of a vector block
-  // the 4-block MFMA of the solve (oc_mv4 below): row r4 = lane & 15, k4 = lane >> 4.  The eight block offsets are bytes of two registers:
-  // every register the solve keeps live across the iteration counts (a spilled offset is a scratch reload with a full wait in front of a chain)
   unsigned f4;       // byte K: element (r4, k4 + 4 K) of a swizzled LDS block
   unsigned t4;       // byte K: element (k4 + 4 K, r4)
   int k4;            // this lane's piece of a vector: v[k4 + 4 K]
   int o4;            // the element of the result this lane holds: 4 ((lane >> 2) & 3) + (lane >> 4)
-  bool col0;         // n == 0 (lane & 15 == 0)
 };
 __device__ __forceinline__ OcLane oc_lane(int lane) {
   OcLane ln;
-  const int n = lane & 15, kk = lane >> 4, r = oc_phi(n);
-  ln.fLo = oc_swz(r, 4 * kk); ln.fHi = oc_swz(r, 4 * kk + 2);
-  ln.t0 = oc_swz(4 * kk, r); ln.t1 = oc_swz(4 * kk + 1, r); ln.t2 = oc_swz(4 * kk + 2, r); ln.t3 = oc_swz(4 * kk + 3, r);
-  ln.vb = 4 * kk; ln.col0 = n == 0;
+  const int n = lane & 15, kk = lane >> 4;
   ln.f4 = 0; ln.t4 = 0;
 #pragma unroll
   for (int K = 0; K < 4; K++) { ln.f4 |= (unsigned)oc_swz(n, kk + 4 * K) << (8 * K); ln.t4 |= (unsigned)oc_swz(kk + 4 * K, n) << (8 * K); }
   ln.k4 = kk; ln.o4 = 4 * ((lane >> 2) & 3) + (lane >> 4);
   return ln;
 }
-__device__ __forceinline__ d4 oc_ldF(const double *blk, const OcLane &ln) {
-  const d2 lo = *reinterpret_cast<const d2 *>(blk + ln.fLo), hi = *reinterpret_cast<const d2 *>(blk + ln.fHi);
-  return d4{lo[0], lo[1], hi[0], hi[1]};
-}
-__device__ __forceinline__ d4 oc_ldT(const double *blk, const OcLane &ln) { return d4{blk[ln.t0], blk[ln.t1], blk[ln.t2], blk[ln.t3]}; }
-__device__ __forceinline__ d4 oc_ldB(const double *vec, int p, const OcLane &ln) { return *reinterpret_cast<const d4 *>(vec + BS * p + ln.vb); }
-// every column of an MFMA result holds the same vector: the 16 lanes of a group store identical data to one address (no exec-masked
-// branch, whose block boundary would cost the chain loops a full LDS wait)
-__device__ __forceinline__ void oc_stB(double *vec, int p, const OcLane &ln, const d4 v) { *reinterpret_cast<d4 *>(vec + BS * p + ln.vb) = v; }
-// acc += Block * v on the matrix cores (a: the block's A-operand registers of this lane, v: the vector in the B layout)
+// acc += A B on the matrix cores, one 16x16x4 step per register pair (the factorisation's products: oc_mm below)
 __device__ __forceinline__ d4 oc_mv(const d4 a, const d4 v, d4 acc) {
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], v[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], v[1], acc, 0, 0, 0);

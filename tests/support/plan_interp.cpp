@@ -331,14 +331,14 @@ extern "C" int plan_check_layout(int n, int m, const int *Pp, const int *Pi, con
   return 0;
 }
 
-// ---- on-chip mode (kernel_onchip.hpp): lane-accurate emulation of the solve -- the MFMA operand / result layouts (v_mfma_f64_16x16x4_f64:
-// A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15], D[m = (l >> 4) + 4 g][n = l & 15]), the index map phi, the swizzled LDS block image
-// read as rows and as columns, the chain tables, the per-wave position slots with phantoms, the junction term and the hub phases -- on the
-// factor the level-parallel plan produces, with a hazard check between the waves of every phase.
+// ---- on-chip mode (kernel_onchip.hpp): lane-accurate emulation of the solve and of the factorisation -- the MFMA operand / result layouts
+// (v_mfma_f64_16x16x4_f64: A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15], D[m = (l >> 4) + 4 g][n = l & 15]; the 4-block
+// v_mfma_f64_4x4x4_4b_f64 further down), the swizzled LDS block image read element by element, the ds_swizzle hand-over of a chain stage, the
+// chain tables, the per-wave position slots with phantoms, the junction term and the hub phases -- on the factor of the level-parallel plan
+// or of the in-register LDL', with a hazard check between the waves of every phase.
 // returns 0 ok, 1 plan error, 2 not positive definite, 3 hazard, 5 the pattern is not taken by the on-chip plan; info: nbc, has_hub, junc, nlds, nhr, lds bytes
 namespace {
 struct Wave { double v[64][4]; };   // one d4 per lane
-inline int phi(int m) { return 4 * (m & 3) + (m >> 2); }
 inline int swz(int r, int c) { return ((r ^ ((r >> 2) & 1)) << 4) | (c ^ (((r >> 1) & 3) << 2) ^ (((r >> 3) & 1) << 1)); }
 void mfma(const double a[64], const double b[64], Wave &acc) {
   double A[16][4], B[4][16];
@@ -352,10 +352,6 @@ void mfma(const double a[64], const double b[64], Wave &acc) {
 void mv(const Wave &a, const Wave &v, Wave &acc) {     // oc_mv: 4 MFMAs, register i of the block against register i of the vector
   for (int i = 0; i < 4; i++) { double x[64], y[64]; for (int l = 0; l < 64; l++) { x[l] = a.v[l][i]; y[l] = v.v[l][i]; } mfma(x, y, acc); }
 }
-Wave ldF(const double *blk) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = blk[swz(r, 4 * kk + i)]; } return w; }
-Wave ldT(const double *blk) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = blk[swz(4 * kk + i, r)]; } return w; }
-Wave ldFg(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = sign * blk[r * BS + 4 * kk + i]; } return w; }
-Wave ldTg(const double *blk, double sign) { Wave w; for (int l = 0; l < 64; l++) { const int r = phi(l & 15), kk = l >> 4; for (int i = 0; i < 4; i++) w.v[l][i] = sign * blk[(4 * kk + i) * BS + r]; } return w; }
 Wave ldB(const double *vec, int p) { Wave w; for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) w.v[l][i] = vec[BS * p + 4 * (l >> 4) + i]; return w; }
 bool stB(double *vec, int p, const Wave &w) {          // every lane of a group stores: they must agree
   for (int l = 0; l < 64; l++) for (int i = 0; i < 4; i++) {
@@ -728,7 +724,8 @@ extern "C" int plan_oc_chains(int n, int m, const int *Pp, const int *Pi, const 
   OcPlan oc = build_oc_plan(pl, 4, 1 << 20, 5, 3);
   if (!oc.ok) return 5;
   int k = 0; out[k++] = (int)oc.chainE.size(); out[k++] = (int)oc.chainF.size(); out[k++] = oc.junc;
-  for (int p : oc.chainE) out[k++] = p; for (int p : oc.chainF) out[k++] = p;
+  for (int p : oc.chainE) out[k++] = p;
+  for (int p : oc.chainF) out[k++] = p;
   return 0;
 }
 
