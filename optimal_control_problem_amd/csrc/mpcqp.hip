@@ -345,7 +345,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
       d.at_poll = d.at_free = -1;
-      if (!getenv("MPCQP_NO_LATE")) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
+      // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
+      if (getenv("MPCQP_LATE")) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));

@@ -373,7 +373,7 @@ def test_onchip_is_the_default_for_the_north_star_size(built):
         assert info["variant"] == want, (name, N, info["variant"])
 
 
-@pytest.mark.parametrize("knob", ["MPCQP_NO_LATE", "MPCQP_NO_REMAP", "MPCQP_NO_TOUCH", "MPCQP_OC_PAD4"])
+@pytest.mark.parametrize("knob", ["MPCQP_LATE", "MPCQP_NO_REMAP", "MPCQP_NO_TOUCH", "MPCQP_OC_PAD4"])
 def test_onchip_scheduling_knobs_change_no_result(built, monkeypatch, knob):
     """which wave computes which rows of the right-hand side and when (late rows, ticket), which wave plays which part, the L2 touch: none of
     it may change a bit of the output; the ELL padding only adds zero slots (same sums)"""
