@@ -1021,11 +1021,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
         }
       }
       bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
-      for (int t = tid; t < npad; t += NT) {
-        const double xo = cx.X[t], xn = alpha * cx.R[t] + (1.0 - alpha) * xo;
-        cx.X[t] = xn;
-        if (save) dxg[t] = xn - xo;
+      if (__builtin_expect(save, 0)) {     // (its own loop: the address of dx stayed live across the iteration otherwise -- spilled, and reloaded here behind a full wait)
+        for (int t = tid; t < npad; t += NT) { const double xo = cx.X[t]; dxg[t] = (alpha * cx.R[t] + (1.0 - alpha) * xo) - xo; }
       }
+      for (int t = tid; t < npad; t += NT) cx.X[t] = alpha * cx.R[t] + (1.0 - alpha) * cx.X[t];
       bsync<NW>();
       TS(6);
       iter_done = iter;
