@@ -246,10 +246,21 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const ResPlan r2 = build_res_plan(p4, 2);
       const long l2 = lds_bytes_res(p4, r2);
       const long q1 = small_ok && l1 <= LDS_MAX ? LDS_MAX / l1 : 0, q2 = small_ok && l2 <= 40 * 1024 ? std::min<long>(LDS_MAX / l2, 6) : 0;
+      auto oc_takes = [&]() {
+        if (getenv("MPCQP_NO_OC") || !small_ok) return false;
+        const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
+        return o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX;
+      };
       if (q2 > cap4 && q2 + 1 >= q1 && !getenv("MPCQP_NO_RES2")) want = 2;
       // the latency regime above; with three or four 4-wave workgroups per CU they stay ahead of one wave per QP up to about three resident
       // rounds (double integrator x2048 1.57 vs 1.81 ms, x4096 2.89 vs 2.76 ms)
-      else if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) want = 4;
+      else if (cap4 > 0 && (long)batch <= cus * cap4 * (cap4 >= 3 ? 3 : 1)) {
+        want = 4;
+        // ... and in it the on-chip mode where it takes the pattern: up to two rounds of its two workgroups per CU it finishes a batch sooner than
+        // the LDS-resident kernel at any occupancy (tools/small_batch_scan.py, x 64 ... 1024: quadrotor N = 5 / 10 / 20 0.21 / 0.43 / 0.85 ms against
+        // 0.24 / 0.52 / 1.08, cart-pole N = 20 / 30 0.73 / 1.12 against 0.89 / 1.41, double integrator N = 30 / 50 1.11 / 1.64 against 1.31 / 2.18)
+        if ((long)batch <= cus * 4 && oc_takes()) { h->gblocks = true; h->oc = true; }
+      }
       // one wave per QP only where it puts more QPs on a CU than the 4-wave kernel has workgroups there (five against four at 28 KiB: +6 %;
       // four against four at 34-36 KiB: the 4-wave kernel is 23-31 % ahead -- double integrator N=24 / 26, cart-pole N=15)
       else if (small_ok && l1 <= 40 * 1024 && LDS_MAX / l1 > cap4) want = 1;
@@ -259,11 +270,6 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         // streamed from the slab (measured, profiles/r02_final_variant_grid.txt, x 8192: quadrotor N = 6 ... 20 +8 ... +48 %, cart-pole N = 30 / 40 / 50
         // +20 / +26 / +37 %, double integrator N = 40 ... 80 +12 ... +64 %).  With three or more resident workgroups per CU the LDS-resident
         // kernels stay ahead (quadrotor N = 5 2.57 vs 2.06 M QP/s, cart-pole N = 20 818k vs 656k, double integrator N = 30 792k vs 611k).
-        auto oc_takes = [&]() {
-          if (getenv("MPCQP_NO_OC") || !small_ok) return false;
-          const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
-          return o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX;
-        };
         // LDS-resident 4-wave kernel while two fit a CU
         if (small_ok && l4 <= 80 * 1024) { want = 4; if (l4 > 53 * 1024 && oc_takes()) { h->gblocks = true; h->oc = true; } }
         // factor streamed from the slab, two waves per QP (168-VGPR instance, six workgroups per CU) while six fit the LDS: ahead of four waves x

@@ -1,0 +1,25 @@
+"""Small-batch kernel time, default selection against the on-chip mode forced: python tools/small_batch_scan.py [workload:horizon ...]"""
+import os, sys
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from optimal_control_problem_amd import models
+from optimal_control_problem_amd.batch_qp import BatchQP
+def run(name, N, B, env):
+    for k in ("MPCQP_VARIANT",): os.environ.pop(k, None)
+    os.environ.update(env)
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    d = [torch.as_tensor(a, device="cuda") for a in (ls.P, ls.q, ls.A, ls.l, ls.u)]
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai); qp.set_dispatch_hint(False)
+    ms=[]
+    for _ in range(5):
+        qp.update(*d); qp.solve(); qp.get(); ms.append(qp.last_kernel_ms())
+    v = qp.plan_info()["variant"]; qp.close()
+    return v, min(ms[1:])
+import sys as _s
+CASES = [(a.split(":")[0], int(a.split(":")[1])) for a in _s.argv[1:]] or [("quadrotor", 20), ("quadrotor", 10), ("cartpole", 30)]
+for name, N in CASES:
+    for B in (64, 256, 512, 1024, 2048):
+        out=[]
+        for env in ({}, {"MPCQP_VARIANT":"oc4"}):
+            v, ms = run(name, N, B, env); out.append("%d: %.3f ms" % (v, ms))
+        print(name, N, "B=%d" % B, " | ".join(out), flush=True)
