@@ -1,0 +1,14 @@
+import os, sys
+sys.path.insert(0, '/root/repo')
+import torch
+from optimal_control_problem_amd import models
+from optimal_control_problem_amd.batch_qp import BatchQP
+for env in ({}, {"MPCQP_VARIANT": "res4"}):
+    os.environ.pop("MPCQP_VARIANT", None); os.environ.update(env)
+    for B in (1, 16):
+        mdl, ls, _ = models.make_workload("quadrotor", B, N=20)
+        d = [torch.as_tensor(a, device="cuda") for a in (ls.P, ls.q, ls.A, ls.l, ls.u)]
+        qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai); ms = []
+        for _ in range(6):
+            qp.update(*d); qp.solve(); out = qp.get(); ms.append(qp.last_kernel_ms())
+        print(env, "B=%d variant %d kernel %.3f ms iters %s" % (B, qp.plan_info()["variant"], min(ms[1:]), out["iters"][:4].tolist())); qp.close()
