@@ -187,38 +187,6 @@ __device__ __forceinline__ d4 mfma_abt_l(const double *A, const double *B, d4 ac
   return acc;
 }
 
-// One wave: in-place inverse of the SPD 16x16 tile `a` (LDS, row-major) by symmetric sweeps; rb = 16 doubles of LDS.
-// Pivots of the sweeps are the Cholesky pivots squared, so "all pivots > 0" is the positive-definiteness test.
-__device__ __forceinline__ bool sweep_inverse(double *a, double *rb, int lane) {
-  const int r = lane >> 2, j = lane & 3;
-  d4 v = reinterpret_cast<const d4 *>(a)[lane];      // a[r][4j .. 4j+3]
-#pragma unroll
-  for (int k = 0; k < BS; k++) {
-    if (r == k) reinterpret_cast<d4 *>(rb)[j] = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const d4 rk = reinterpret_cast<const d4 *>(rb)[j];
-    const double colk = rb[r], d = rb[k];
-    if (!(d > 0.0)) return false;                       // uniform
-    const double p = 1.0 / d;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int col = 4 * j + c;
-      double nv;
-      if (r != k && col != k) nv = v[c] - colk * rk[c] * p;
-      else if (r == k && col != k) nv = rk[c] * p;
-      else if (r != k && col == k) nv = colk * p;
-      else nv = -p;
-      v[c] = nv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  reinterpret_cast<d4 *>(a)[lane] = -v;
-  return true;
-}
-
 // ---- solve-schedule executor -------------------------------------------------------------------------------
 // A lone wave issues roughly one instruction per 4-8 cycles, so the executor is written for instruction count:
 // the host compresses each wave's op list into segments whose block / src / dst byte offsets are arithmetic
@@ -535,8 +503,13 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
 #ifdef MPCQP_TIMING
     const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
 #endif
-    for (int ci = rs.lv_ptr[lev] + wid; ci < rs.lv_ptr[lev + 1]; ci += NW)
-      ok = sweep_inverse(cx.BL + (long)rs.lv_diag[ci] * BLK, cx.RB + 16 * wid, lane) && ok;
+    for (int ci = rs.lv_ptr[lev] + wid; ci < rs.lv_ptr[lev + 1]; ci += NW) {
+      // (the in-register inverse of the on-chip mode, kernel_onchip.hpp oc_sweep: 16 rank-1 MFMAs instead of 16 LDS round trips)
+      double *blk = cx.BL + (long)rs.lv_diag[ci] * BLK;
+      d4 dg = oc_ldD(blk, lane);
+      ok = oc_sweep(dg, lane) && ok;
+      oc_stD(blk, lane, dg);
+    }
 #ifdef MPCQP_TIMING
     if (wid == 0) cx.fts[3] += __builtin_amdgcn_s_memtime() - s0_;
 #endif
