@@ -191,13 +191,13 @@ constexpr int OC_LDL_SCR = 8;     // LDS scratch blocks of oc_ldl (the stage reg
 template <int NW, bool HUB>
 __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double *slab, double *scr, double *red, const int wid, const int lane,
                                        unsigned long long *t_sweep = nullptr) {
-  static_assert(NW == 4, "two chain waves and their two helpers");
+  static_assert(NW >= 4, "two chain waves and their two helpers (further waves only take part in the barriers)");
   // scratch blocks: 0..3 G hand-over [chain][step parity], 4 chain E's term for the junction's diagonal block, 5 for its hub block, 6..7 the helpers' sums
   const int LE = oc_tab(ctab, 0), LF = oc_tab(ctab, 1);
   const bool junc = oc.junc && LF > 0;
   const int S = junc ? max(LE + 1, LF) : LE;          // chain steps run in phases 0 .. S - 1 (chain F keeps its last step, the junction, for phase S - 1); helpers one phase behind
   const int ch = wid & 1;
-  const bool helper = wid >= 2;
+  const bool helper = wid == 2 || wid == 3, idle = wid >= 4;
   const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
   const int *pt = oc.tab + oc.o_pos;
   // block ids of the chain's steps, step i in lane i (read back with v_readlane: no memory latency inside a phase)
@@ -221,13 +221,14 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
     if (!last || tojunc) Ln = oc_ldA(slab + (long)__builtin_amdgcn_readlane(csv, k) * BLK, lane);
     if (!last) Sn = oc_ldD(slab + (long)__builtin_amdgcn_readlane(gsv, k + 1) * BLK, lane);
   };
-  if (L > 0) {
+  if (L > 0 && !idle) {
     if (!helper) { Dc = oc_ldD(slab + (long)__builtin_amdgcn_readlane(gsv, 0) * BLK, lane); chain_fetch(0); }
     else if (HUB) Hr = oc_ldA(slab + (long)__builtin_amdgcn_readlane(hsv, 0) * BLK, lane);
   }
   const int nph = HUB ? S + 1 : S;
   for (int s = 0; s < nph; s++) {
-    if (!helper) {
+    if (idle) {
+    } else if (!helper) {
       if (pend >= 0) { oc_stA(slab + (long)pend * BLK, lane, Wp); pend = -1; }     // one phase late: the helper has read L by now
       const int k = step_of(s);
       if (k >= 0) {
@@ -278,7 +279,7 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
     }
     bsync<NW>();
   }
-  if (!helper && pend >= 0) oc_stA(slab + (long)pend * BLK, lane, Wp);
+  if (!helper && !idle && pend >= 0) oc_stA(slab + (long)pend * BLK, lane, Wp);
   if (HUB) {
     if (helper) oc_stS(scr + (6 + ch) * BLK, lane, Sh);
     bsync<NW>();
@@ -307,7 +308,7 @@ struct OcWave {
   int ok[NG];        // the slot has a position
 };
 constexpr int OC_MAXT = 8;       // chain loops are unrolled for up to 2 * OC_MAXT stages + 1: chains of at most 17 positions (plan.hpp checks)
-constexpr int OC_ZERO = 5;       // vector blocks behind the solve vector: 0 junction term, 1..4 hub partial sums, 5 zeros
+// vector blocks behind the solve vector: 0 junction term, 1..NW hub partial sums, NW + 1 zeros (plan.hpp oc_rext)
 template <int NW, int NG, int NH>
 __device__ __forceinline__ OcWave<NG> oc_wave(const DevOc &oc, const int *tab, const int wid, const int npad) {
   OcWave<NG> ow;
@@ -315,7 +316,7 @@ __device__ __forceinline__ OcWave<NG> oc_wave(const DevOc &oc, const int *tab, c
   for (int s = 0; s < NG; s++) {
     const int p = wid + NW * s, pe = p < oc.nbc ? p : oc.nbc - 1;
     ow.ok[s] = p < oc.nbc;
-    ow.vpos[s] = p < oc.nbc ? p : npad / BS + OC_ZERO;
+    ow.vpos[s] = p < oc.nbc ? p : npad / BS + NW + 1;
     const int hs = oc_tab(tab, oc.o_pos + 5 * pe + 4);
     ow.hslot[s] = hs >= 0 ? hs : 0;
   }
@@ -378,13 +379,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     d4 x = oc_ldB4(R, e0.x, ln), y = x;
     d4 a = oc_ldF4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e1.x, ln);
     int k = 0;
-#pragma unroll
-    for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
-      if (k + 2 > nst) break;
-      if (trip == OC_POLL_TRIP && oc.at_poll >= 0) {     // the late rows of the right-hand side are in place from here on
-        while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
+    auto trip2 = [&]() {
       // stage k: t = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
       const d4 a1 = oc_ldF4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e2.x, ln);
       const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
@@ -401,6 +396,22 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
       __builtin_amdgcn_sched_barrier(0);
       oc_stB4(R, e2.x, ln, r1);
       e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
+    };
+    if constexpr (NW == 4) {
+#pragma unroll
+      for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
+        if (k + 2 > nst) break;
+        if (trip == OC_POLL_TRIP && oc.at_poll >= 0) {     // the late rows of the right-hand side are in place from here on
+          while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        trip2();
+      }
+    } else {
+      // long chains (eight-wave instances): the same trip as a loop -- the carried values are the block, the right-hand side element, the
+      // operand and four table entries, all rewritten inside the trip
+#pragma unroll 1
+      while (k + 2 <= nst) trip2();
     }
     if (k < nst) {                                     // odd stage count: one more
       const double r0 = oc_mv4x4(a, x, c);
@@ -423,29 +434,22 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
   double xhd = 0.0;           // ... and as its element of the result (o4)
   constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
   if (HUB) {
-    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions
+    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions, NA of them multiplied together
     double hsum = 0.0;
-    {
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += NA) {
       d4 t[NA], a[NA]; double acc[NA];
 #pragma unroll
-      for (int s = 0; s < NA; s++) { t[s] = oc_ldB4(R, ow.vpos[s], ln); a[s] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s] = 0.0; }
+      for (int u = 0; u < NA; u++) {
+        const int s = g0 + u;
+        if (s < NG) { t[u] = oc_ldB4(R, ow.vpos[s < NG ? s : 0], ln); a[u] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s < NG ? s : 0] * BLK, ln); acc[u] = 0.0; }
+      }
 #pragma unroll
       for (int K = 0; K < 4; K++)
 #pragma unroll
-        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(a[s][K], t[s][K], acc[s]);
+        for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(a[u][K], t[u][K], acc[u]);
 #pragma unroll
-      for (int s = 0; s < NA; s++) hsum += acc[s];
-    }
-    if (NG > NA) {
-      d4 t[NG - NA > 0 ? NG - NA : 1], a[NG - NA > 0 ? NG - NA : 1]; double acc[NG - NA > 0 ? NG - NA : 1];
-#pragma unroll
-      for (int s = NA; s < NG; s++) { t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); a[s - NA] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s - NA] = 0.0; }
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(a[s - NA][K], t[s - NA][K], acc[s - NA]);
-#pragma unroll
-      for (int s = NA; s < NG; s++) hsum += acc[s - NA];
+      for (int u = 0; u < NA; u++) if (g0 + u < NG) hsum += acc[u];
     }
     oc_stB4(EXT, 1 + wid, ln, hsum);
     bsync<NW>();
@@ -462,46 +466,29 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
   }
   OC_TS(1);
   // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
-  {
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += NA) {
     d4 t[NA], g[NA], h[NA]; double acc[NA];
 #pragma unroll
-    for (int s = 0; s < NA; s++) {
-      t[s] = oc_ldB4(R, ow.vpos[s], ln); g[s] = G[s]; acc[s] = 0.0;
-      if (HUB) h[s] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
+    for (int u = 0; u < NA; u++) {
+      const int s = g0 + u;
+      if (s < NG) {
+        t[u] = oc_ldB4(R, ow.vpos[s < NG ? s : 0], ln); g[u] = G[s < NG ? s : 0]; acc[u] = 0.0;
+        if (HUB) h[u] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s < NG ? s : 0] * BLK, ln);
+      }
     }
 #pragma unroll
     for (int K = 0; K < 4; K++)
 #pragma unroll
-      for (int s = 0; s < NA; s++) acc[s] = oc_mv4(g[s][K], t[s][K], acc[s]);
+      for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(g[u][K], t[u][K], acc[u]);
     if (HUB) {
 #pragma unroll
       for (int K = 0; K < 4; K++)
 #pragma unroll
-        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(h[s][K], xh[K], acc[s]);
+        for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(h[u][K], xh[K], acc[u]);
     }
 #pragma unroll
-    for (int s = 0; s < NA; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s]);
-  }
-  if (NG > NA) {
-    constexpr int NB = NG - NA > 0 ? NG - NA : 1;
-    d4 t[NB], g[NB], h[NB]; double acc[NB];
-#pragma unroll
-    for (int s = NA; s < NG; s++) {
-      t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); g[s - NA] = G[s]; acc[s - NA] = 0.0;
-      if (HUB) h[s - NA] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
-    }
-#pragma unroll
-    for (int K = 0; K < 4; K++)
-#pragma unroll
-      for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(g[s - NA][K], t[s - NA][K], acc[s - NA]);
-    if (HUB) {
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(h[s - NA][K], xh[K], acc[s - NA]);
-    }
-#pragma unroll
-    for (int s = NA; s < NG; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s - NA]);
+    for (int u = 0; u < NA; u++) if (g0 + u < NG) { if (ow.ok[g0 + u < NG ? g0 + u : 0]) oc_stB4(R, ow.vpos[g0 + u < NG ? g0 + u : 0], ln, acc[u]); }
   }
   bsync<NW>();
   OC_TS(2);
@@ -517,9 +504,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
       int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
       d4 y = x;
       d4 a = oc_ldT4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e0.x, ln);
-#pragma unroll
-      for (int trip = 0; trip < OC_MAXT; trip++) {
-        if (k < 1) break;
+      auto trip2 = [&]() {
         const d4 a1 = oc_ldT4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e1.x, ln);
         const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
         __builtin_amdgcn_sched_barrier(0);
@@ -534,6 +519,16 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
         __builtin_amdgcn_sched_barrier(0);
         oc_stB4(R, e1.x, ln, r1);
         e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
+      };
+      if constexpr (NW == 4) {
+#pragma unroll
+        for (int trip = 0; trip < OC_MAXT; trip++) {
+          if (k < 1) break;
+          trip2();
+        }
+      } else {
+#pragma unroll 1
+        while (k >= 1) trip2();
       }
       if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
     }

@@ -706,13 +706,14 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
   constexpr bool OC = OCG > 0;
-  static_assert(!OC || (GB && !ZYG && NW == 4), "the on-chip solve is a mode of the 4-wave global-block kernel");
+  static_assert(!OC || (GB && (NW == 4 || NW == 8)), "the on-chip solve is a mode of the 4- and 8-wave global-block kernels");
+  constexpr int OCU = NW == 4 ? 16 : 8;      // on-chip mode: ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
   constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
   constexpr int EU = OC ? 8 : 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower; the on-chip mode needs the registers)
   const int lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
   int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if constexpr (OC) {
+  if constexpr (OC && NW == 4) {
     // Which wave plays which part is free.  The two workgroups of a CU put their chain waves (0, 1: the only ones busy in the chain phases of
     // the solve, bound by dependent MFMAs) on different SIMDs: the wave on SIMD s of the workgroup in LDS slot k takes part (s + 2 k) mod 4.
     // HW_ID[5:4] = SIMD, LDS_ALLOC[7:0] = LDS base (0: the CU's first slot).  Only when the four waves do sit on four SIMDs.
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     const int c = w == 3 ? oc.at_poll : oc.at_free;
     if (c >= 0) {
       const int t = c * WAVE + lane;
-      const double v = ell_chunk<false, 16>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
+      const double v = ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
       if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
     }
   };
@@ -931,7 +932,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   auto idle_touch = [&](const int w) {
     if (io.no_touch) return;
     if (w == 2) oc_touch(valA, pl.A.entries * 8, lane);
-    else { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
+    else if (w == 3) { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
   };
   if (ok) {
     int iter;
@@ -939,7 +940,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       if constexpr (OC) {     // (the chunks named in oc.at_poll / oc.at_free are computed during the chain phase of the solve: oc_solve)
         for (int c = wid; c < pl.At.nchunks; c += NW) if (c != oc.at_poll && c != oc.at_free) {
           const int t = c * WAVE + lane;
-          const double v = ell_chunk<false, 16>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
+          const double v = ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, cx.coAt[c], cx.coAt[c + 1], lane);
           if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
         }
       } else
@@ -989,7 +990,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
           const double lo = lb[i], up = ub[i];
           // z, y of this row as well when they live in the slab: their latency hides behind the row sum like that of l, u
           const double zo = (GB && ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (GB && ZYG && i < mpad) ? cx.Y[i] : 0.0;   // (the last chunk may run past mpad)
-          const double zt = ell_chunk<false, (OC ? 16 : EU)>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
+          const double zt = ell_chunk<false, (OC ? OCU : EU)>(valA, pl.A.idx, cx.R, cx.coA[c], cx.coA[c + 1], lane);
           row_update(i, lo, up, zo, yp, zt);
         }
       }

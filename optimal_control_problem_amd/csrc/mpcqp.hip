@@ -81,6 +81,7 @@ struct mpcqp_handle {
   bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   bool oc = false;              // on-chip mode of the global-block kernel (kernel_onchip.hpp): two workgroups per CU, factor in LDS + registers
+  int oc8 = 0;                  // ... its eight-wave instances for long chains (one workgroup per CU): 1 = <NG 4, NH 4>, 2 = <NG 7, NH 5, z / y in the slab>
   OcPlan ocplan; DevOc doc;
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
@@ -134,11 +135,21 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 // register-resident blocks per wave of the on-chip instance: inverse diagonal blocks (positions per wave) and hub blocks
 constexpr int OC_NG = 5, OC_NH = 3;
 constexpr long OC_LDS_MAX = 80 * 1024;      // two workgroups per CU
+// Long chains (more than 20 chain blocks: quadrotor N > 20, cart-pole N > 60): eight waves per QP, one workgroup per CU -- the whole LDS and
+// 8 x 256 VGPRs for one factor.  Two instances: up to 32 chain blocks with every hub block in registers (cart-pole N = 100: 62 KB of chain
+// blocks + 36 KB of vectors in LDS), and up to 56 with five hub blocks per wave in registers, the rest in LDS, and z, y in the slab
+// (quadrotor N = 50: 49 chain blocks + 10 hub blocks + the hub's inverse = 120 KB, 35 KB of vectors)
+struct Oc8Inst { int ng, nh; bool zyg; };
+constexpr Oc8Inst OC8_INST[2] = {{4, 4, false}, {7, 5, true}};
+constexpr long OC8_LDS_MAX = 160 * 1024;
+constexpr int OC8_MAX_CHAIN = 64;           // (oc_ldl keeps the chain's block ids one per lane)
 
 // the kernel instance a handle runs: waves per QP, register budget, factor location, and -- as its own instance so that the
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->oc && h->oc8 == 1) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[0].zyg, OC8_INST[0].ng, OC8_INST[0].nh>;
+  if (h->oc && h->oc8 == 2) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh>;
   if (h->oc) return h->ocplan.has_hub ? (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, 0>;
   if (h->gblocks && h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, true, REUSE>;
   if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
@@ -216,6 +227,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       else if (v == "res2") want = 2;
       else if (v == "gres2") { want = 2; h->gblocks = true; }
       else if (v == "oc4") { want = 4; h->gblocks = true; h->oc = true; }
+      else if (v == "oc8") { want = 8; h->gblocks = true; h->oc = true; h->oc8 = -1; }
     }
     // candidate plans of the multi-wave kernels: ELL chunk widths padded to multiples of 4 (fewer load batches per chunk)
     // and the stage chain eliminated from both ends (two concurrent half-length chains)
@@ -282,7 +294,24 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         else want = 0;
       }
     }
-    if (h->oc) {
+    // Long chains: where the rules above arrive at a factor streamed from the slab, the eight-wave on-chip instances take the pattern if it is
+    // a block chain with an arrow head of up to 56 blocks that fits one CU (MPCQP_NO_OC8 keeps the global-block kernels)
+    if ((h->oc8 < 0 || (want > 0 && h->gblocks && !h->oc && !getenv("MPCQP_VARIANT") && !getenv("MPCQP_NO_OC8") && !getenv("MPCQP_NO_OC"))) && small_ok) {
+      Plan p8 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 3 : -1, 2);
+      h->oc8 = 0;
+      if (p8.error.empty()) {
+        const ResPlan r8 = build_res_plan(p8, 8, false);
+        for (int k = 0; k < 2 && !h->oc8; k++) {
+          const OcPlan o = build_oc_plan(p8, 8, 1 << 20, OC8_INST[k].ng, OC8_INST[k].nh, OC8_MAX_CHAIN);
+          if (o.ok && o.has_hub && lds_bytes_oc(p8, r8, o, OC8_INST[k].zyg) <= OC8_LDS_MAX) {
+            h->ocplan = o; h->oc8 = k + 1; h->oc = true; h->gblocks = true; h->zyg = OC8_INST[k].zyg; want = 8; p4 = p8;
+          }
+        }
+      }
+      if (!h->oc8 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc8")
+        return bail(fail(MPCQP_ERR_LIMIT, "the eight-wave on-chip variant does not take this pattern / size"));
+    }
+    if (h->oc && !h->oc8) {
       // on-chip mode: block tridiagonal + arrow patterns whose factor fits LDS + the registers of the instance at two workgroups per CU
       const ResPlan r4 = build_res_plan(p4, 4, false);
       h->oc = false;
@@ -298,7 +327,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want, h->gblocks && !h->oc);
-      long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
       if (h->gblocks && !h->oc && !getenv("MPCQP_NO_ZYG")) {
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
         const long alt = lds_bytes_res_gb(pl, h->rplan, true);
@@ -347,7 +376,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     memset(&h->doc, 0, sizeof(h->doc));
     if (h->oc) {
       const OcPlan &o = h->ocplan; DevOc &d = h->doc;
-      dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = OC_REXT; dr.nconst = 0; dr.n_seg = 0;
+      dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = oc_rext(rp.nw); dr.nconst = 0; dr.n_seg = 0;
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
       d.at_poll = d.at_free = -1;
@@ -584,7 +613,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (h->inner) return solve_reduced(h, s);
   DevIO io = h->io;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = getenv("MPCQP_NO_TOUCH") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = (getenv("MPCQP_NO_TOUCH") || (h->oc8 && !getenv("MPCQP_TOUCH8"))) ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
@@ -663,7 +692,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
   DevIO io = h->io;
   io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = getenv("MPCQP_NO_TOUCH") ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = (getenv("MPCQP_NO_TOUCH") || (h->oc8 && !getenv("MPCQP_TOUCH8"))) ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = 0; io.keep = h->keep ? 1 : 0; io.order = nullptr;
   if (sP == 0 && wP) HIPCHK(hipMemcpy(h->dP, P, wP * sizeof(double), hipMemcpyHostToDevice));      // shared matrices: once
   if (sA == 0 && wA) HIPCHK(hipMemcpy(h->dA, A, wA * sizeof(double), hipMemcpyHostToDevice));

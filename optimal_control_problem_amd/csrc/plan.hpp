@@ -242,7 +242,7 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
   // [0, k-1, 1, k-2, ...]: the elimination tree becomes two chains that meet in the middle -- same block count, half
   // the sequential depth (two waves eliminate / substitute concurrently).
   bool twisted = false;
-  if (force_ordering == 2) {
+  if (force_ordering >= 2) {
     int nonhub = 0;   // hubs sit behind all non-hubs; count the leading variables that kept relative order 0..r-1
     {
       std::vector<int> inv(n, -1);
@@ -251,8 +251,19 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
       nonhub = n;
       for (int t = 1; t < n; t++) if (inv[t] < inv[t - 1]) { nonhub = t; break; }
     }
-    const int k = nonhub / BS;
-    if (nonhub % BS == 0 && k >= 4) {
+    // ordering 3: the same, for chains whose last block is only partly filled (cart-pole: 500 stage variables = 31 1/4 blocks): the hubs move
+    // up to the next block boundary -- padding positions inside the vector, one more block row -- so that the chain part is whole blocks
+    // and can be twisted; accepted when that costs at most four blocks
+    std::vector<int> pos_pad(pos_hub);
+    int npad_pad = npad_hub;
+    const bool padded = force_ordering == 3 && nonhub % BS != 0 && nonhub < n;
+    if (padded) {
+      const int shift = (nonhub + BS - 1) / BS * BS - nonhub;
+      for (int v = 0; v < n; v++) if (pos_hub[v] >= nonhub) pos_pad[v] = pos_hub[v] + shift;
+      npad_pad = ((n + shift + BS - 1) / BS) * BS;
+    }
+    const int k = (nonhub + BS - 1) / BS;
+    if ((nonhub % BS == 0 || padded) && k >= 4) {
       std::vector<std::set<int>> badj(k);
       bool path = true;
       for (int v = 0; v < n && path; v++) if (pos_hub[v] < nonhub) for (int w : adj[v]) if (pos_hub[w] < nonhub) {
@@ -260,12 +271,12 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
         if (std::abs(a - b) > 1) { path = false; break; }
       }
       if (path) {
-        std::vector<int> pos_tw(pos_hub);
+        std::vector<int> pos_tw(pos_pad);
         for (int v = 0; v < n; v++) if (pos_hub[v] < nonhub) {
           const int b = pos_hub[v] / BS, nbk = b < (k + 1) / 2 ? 2 * b : 2 * (k - 1 - b) + 1;
           pos_tw[v] = nbk * BS + pos_hub[v] % BS;
         }
-        if (eval_gap(pos_tw, npad_hub, nullptr) <= c_hub) { pos_hub = pos_tw; twisted = true; }
+        if (eval_gap(pos_tw, npad_pad, nullptr) <= c_hub + (padded ? 4 : 0)) { pos_hub = pos_tw; npad_hub = npad_pad; twisted = true; }
       }
     }
   }
@@ -688,12 +699,13 @@ struct OcPlan {
   std::vector<int> tab;
   int o_chainE = 0, o_chainF = 0, o_pos = 0, o_fill = 0;
 };
-constexpr int OC_REXT = 6 * BS;             // behind the solve vector: the junction term, one hub partial sum per wave, a zero block
+inline int oc_rext(int nw) { return (nw + 2) * BS; }     // behind the solve vector: the junction term, one hub partial sum per wave, a zero block
+constexpr int OC_CHAIN_SHORT = 17;          // the four-wave instances unroll their chain loops for 16 stages (kernel_onchip.hpp OC_MAXT); the eight-wave ones loop
 
-inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_npw, int max_nhr) {
+inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_npw, int max_nhr, int max_chain = OC_CHAIN_SHORT) {
   OcPlan oc;
   const int nb = pl.nb;
-  if (nb < 2 || nw != 4) return oc;
+  if (nb < 2 || (nw != 4 && nw != 8)) return oc;
   std::map<std::pair<int, int>, int> bid;
   for (int b = 0; b < pl.nblk; b++) bid[{pl.blkI[b], pl.blkJ[b]}] = b;
   const int H = nb - 1;
@@ -730,7 +742,7 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
     oc.chainE = c0;
   }
   if ((int)(oc.chainE.size() + oc.chainF.size()) != nbc) return oc;
-  if (oc.chainE.size() > 17 || oc.chainF.size() > 17) return oc;        // the kernel's chain loops are unrolled for 16 stages (OC_MAXT)
+  if ((int)oc.chainE.size() > max_chain || (int)oc.chainF.size() > max_chain) return oc;        // (the four-wave kernels' chain loops are unrolled for 16 stages)
   oc.npw = (nbc + nw - 1) / nw;
   if (oc.npw > max_npw) return oc;
   oc.gsrc.assign(nbc, -1); oc.csrc.assign(nbc, -1); oc.hsrc.assign(nbc, -1); oc.cslot.assign(nbc, -1); oc.hslot.assign(nbc, -1);
@@ -802,10 +814,10 @@ inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp, const Plan &pl
   // block slots / temp tiles, or the factorisation's scratch: 8 hand-over blocks + the assembly records (4 doubles per block)
   return std::max((long)std::max(oc.nlds, rp.ntemp) * BLK, 8L * BLK + ((4L * pl.nblk + 15) / 16) * 16);   // (8: kernel_onchip.hpp OC_LDL_SCR)
 }
-inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc) {
+inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc, bool zy_global = false) {
   // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
   const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1 + 1) / 2;     // (+ the ticket of the late right-hand side rows)
-  return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + OC_REXT + 3L * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
+  return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + oc_rext(rp.nw) + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {

@@ -519,14 +519,17 @@ int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
 }
 }  // namespace
 
-extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH, int ldl,
-                               const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
-  const int nw = 4;
-  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, true);
+// nw = 4: the two-workgroups-per-CU instances (twisted order, chains of at most 17 positions); nw = 8: the long-chain instances (padded
+// twist -- ordering 3 --, chains of any length, zyg: z and y in the slab for the LDS figure)
+extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw, int NG, int NH, int ldl, int zyg,
+                                  const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  if (nw != 4 && nw != 8) return 1;
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, nw == 8 ? 3 : 2, nw == 8 ? 2 : 1);
   if (!pl.error.empty()) return 1;
   ResPlan rp = build_res_plan(pl, nw, false);
-  OcPlan oc = build_oc_plan(pl, nw, 1 << 20, NG, NH);
-  if (info) { info[0] = oc.nbc; info[1] = oc.has_hub; info[2] = oc.junc; info[3] = oc.nlds; info[4] = oc.nhr; info[5] = oc.ok ? lds_bytes_oc(pl, rp, oc) : 0; }
+  OcPlan oc = build_oc_plan(pl, nw, 1 << 20, NG, NH, nw == 8 ? 64 : OC_CHAIN_SHORT);
+  if (info) { info[0] = oc.nbc; info[1] = oc.has_hub; info[2] = oc.junc; info[3] = oc.nlds; info[4] = oc.nhr; info[5] = oc.ok ? lds_bytes_oc(pl, rp, oc, zyg != 0) : 0;
+              info[6] = (long)oc.chainE.size(); info[7] = (long)oc.chainF.size(); }
   if (!oc.ok) return 5;
   // ---- factor (as plan_execute_res: assembly + level-parallel LDL')
   std::vector<double> vA, vAt, vP;
@@ -584,7 +587,7 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   }
   std::vector<std::vector<Wave>> G(nw, std::vector<Wave>(NG, zero())), HF(nw, std::vector<Wave>(std::max(NH, 1), zero())), HT = HF;
   std::vector<std::vector<int>> vpos(nw, std::vector<int>(NG)), hslot = vpos, okp = vpos;
-  const int zero_blk = pl.npad / BS + 5;
+  const int zero_blk = pl.npad / BS + nw + 1;
   for (int w = 0; w < nw; w++) for (int s = 0; s < NG; s++) {
     const int p = w + nw * s, pe = p < oc.nbc ? p : oc.nbc - 1;
     okp[w][s] = p < oc.nbc; vpos[w][s] = p < oc.nbc ? p : zero_blk;
@@ -596,13 +599,13 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
     }
   }
   // ---- oc_solve
-  std::vector<double> R((size_t)pl.npad + OC_REXT, 0.0);
+  std::vector<double> R((size_t)pl.npad + oc_rext(nw), 0.0);
   for (int j = 0; j < n; j++) R[pl.pos[j]] = rhs[j];
   double *EXT = &R[pl.npad];
   const int LE = tab[0], LF = tab[1], H = oc.nbc, f = (oc.junc && LF > 0) ? tab[oc.o_chainF + 2 * (LF - 1)] : -1;
   const bool HUB = NH > 0;
   if (HUB != (oc.has_hub != 0)) return 5;
-  std::vector<int> wr(pl.nb + 6, -1), rd(pl.nb + 6, 0);      // hazard tracking per vector block within a phase
+  std::vector<int> wr(pl.nb + nw + 2, -1), rd(pl.nb + nw + 2, 0);      // hazard tracking per vector block within a phase
   bool hazard = false;
   auto touch = [&](int w, int blk, bool write) {
     if (wr[blk] >= 0 && wr[blk] != w) hazard = true;
@@ -687,6 +690,11 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   if (hazard) return 3;
   for (int j = 0; j < n; j++) sol[j] = R[pl.pos[j]];
   return 0;
+}
+
+extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH, int ldl,
+                               const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  return plan_execute_oc_nw(n, m, Pp, Pi, Ap, Ai, 4, NG, NH, ldl, 0, Pval, Aval, rho, sigma, rhs, sol, info);
 }
 
 // chunk widths of the three ELL structures (diagnostic): out = [nA, widths..., nAt, widths..., nP, widths...]

@@ -341,6 +341,33 @@ def test_onchip_variant_vs_oracle(built, monkeypatch, name, batch, N):
         _close(got, ref, k)
 
 
+@pytest.mark.parametrize("name,batch,N", [("quadrotor", 12, 50), ("cartpole", 12, 100), ("quadrotor", 9, 30), ("cartpole", 7, 70), ("double_integrator", 12, 100),
+                                          ("quadrotor", 6, 25), ("quadrotor", 5, 40), ("cartpole", 4, 150)])
+def test_onchip_long_chains_vs_oracle(built, monkeypatch, name, batch, N):
+    """the eight-wave on-chip instances (one workgroup per CU; chain loops of any length; padded twist for chains whose last block is
+    partly filled -- cart-pole -- ; every hub block in registers up to 32 chain blocks, beyond that five per wave with z and y in the
+    slab): BASELINE configs 3 and 4 and the sizes around them, same bar as every other family"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "oc8")
+    mdl, ls, _ = models.make_workload(name, batch, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info()
+    assert info["variant"] == 208 and info["lds_bytes"] <= 160 * 1024
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+
+
+def test_onchip_long_chains_are_the_default_for_configs_3_and_4(built):
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    for name, N, B in [("quadrotor", 50, 8192), ("cartpole", 100, 16384)]:
+        mdl, ls, _ = models.make_workload(name, 2, N=N)
+        qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+        assert info["variant"] == 208, (name, info)
+
+
 @pytest.mark.parametrize("name,B,N", [("quadrotor", 9, 20), ("cartpole", 5, 40)])
 def test_onchip_variant_without_hub(built, monkeypatch, name, B, N):
     """the reduced form has no parameter block, so its pattern is block tridiagonal without an arrow head: the on-chip instance
@@ -422,7 +449,8 @@ def test_kernel_variants_hard_cases(built, monkeypatch, variant):
 # ---------------------------------------------------------------------------------------------- kept workspace
 @pytest.mark.parametrize("variant,name,B,N", [(None, "double_integrator", 24, 20), ("res1", "double_integrator", 24, 20),
                                               ("gres4", "double_integrator", 24, 20), ("res4", "cartpole", 12, 30),
-                                              ("gres4", "quadrotor", 10, 10), ("oc4", "quadrotor", 10, 20), ("oc4", "double_integrator", 24, 20)])
+                                              ("gres4", "quadrotor", 10, 10), ("oc4", "quadrotor", 10, 20), ("oc4", "double_integrator", 24, 20),
+                                              ("oc8", "quadrotor", 6, 30), ("oc8", "cartpole", 6, 100)])
 def test_kept_workspace_vectors_vs_oracle(built, monkeypatch, variant, name, B, N):
     """mpcqp_keep_workspace + mpcqp_update_vectors (OSQP's osqp_update_data_vec on a kept workspace: scaling, factor and the
     adapted rho stay) against the oracle's kept workspaces, on every kernel family: a full solve, a q/l/u-only solve, a

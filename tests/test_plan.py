@@ -189,6 +189,53 @@ def test_onchip_plan_emulated(built, name, N, expect, ldl):
         assert info["lds"] <= 80 * 1024                   # two workgroups per CU
 
 
+def _run_oc8(ls, NG, NH, zyg, b=0, seed=0, ldl=1):
+    """the eight-wave on-chip plan (ordering 3: padded twist; chains of any length) through the same emulation"""
+    L = C.CDLL(SO)
+    L.plan_execute_oc_nw.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 3
+    rng = np.random.default_rng(seed)
+    n, m = ls.n, ls.m
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(8, np.int64)
+    Pv = np.ascontiguousarray(np.broadcast_to(ls.P, (ls.batch, len(ls.Pi)))[b]); Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[b])
+    rc = L.plan_execute_oc_nw(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), 8, NG, NH, ldl, zyg, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
+    if rc == 0:
+        ref = np.linalg.solve(M, rhs)
+        assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
+    return rc, dict(nbc=info[0], has_hub=info[1], junc=info[2], nlds=info[3], nhr=info[4], lds=info[5], LE=info[6], LF=info[7])
+
+
+@pytest.mark.parametrize("name,N,inst,expect", [("quadrotor", 50, (7, 5, 1), dict(nbc=50, has_hub=1, junc=1, nlds=60, LE=24, LF=26)),       # BASELINE config 3: 49 chain + 10 hub blocks + the hub's inverse in LDS
+                                                ("cartpole", 100, (4, 4, 0), dict(nbc=32, has_hub=1, junc=1, nlds=32, LE=15, LF=17)),        # config 4: padded twist, two chains instead of one of 31
+                                                ("quadrotor", 30, (4, 4, 0), dict(nbc=30, junc=1)), ("quadrotor", 40, (7, 5, 1), dict(nbc=40)),
+                                                ("cartpole", 150, (7, 5, 1), dict(nbc=47, junc=1)), ("double_integrator", 100, (4, 4, 0), dict(nbc=19))])
+@pytest.mark.parametrize("ldl", [0, 1])
+def test_onchip_long_chain_plan_emulated(built, name, N, inst, expect, ldl):
+    """the eight-wave instances' tables (kernel_onchip.hpp with NW = 8: per-wave partial sums 1 .. 8 and the zero block behind them, positions
+    p = w + 8 s, idle waves in the factorisation) on the sizes the four-wave plan refuses"""
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    rc, info = _run_oc8(ls, *inst, b=1, ldl=ldl)
+    assert rc == 0, (rc, info)
+    for k, v in expect.items():
+        assert info[k] == v, (k, info)
+    assert info["lds"] <= 160 * 1024                       # one workgroup per CU
+    if N > 20 and name == "quadrotor":
+        assert _run_oc(ls)[0] == 5                         # ... and the four-wave plan does not take it
+
+
+def test_onchip_long_chain_plan_limits(built):
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=57)          # 57 chain blocks: more than seven positions per wave
+    assert _run_oc8(ls, 7, 5, 1)[0] == 5
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=40)          # 40 positions do not fit the <4, 4> instance
+    assert _run_oc8(ls, 4, 4, 0)[0] == 5 and _run_oc8(ls, 7, 5, 1)[0] == 0
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=56)          # the tables exist, but the LDS of one CU does not hold it: mpcqp_create keeps the global-block kernel
+    rc, info = _run_oc8(ls, 7, 5, 1)
+    assert rc == 0 and info["lds"] > 160 * 1024
+
+
 def test_onchip_plan_without_hub_and_limits(built):
     """the reduced form's pattern (no parameter block): two chains meeting in their last element, no hub phases; sizes past the
     instance's limits are refused by the plan, not mis-executed"""

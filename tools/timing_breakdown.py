@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-segment cycle breakdown of the resident kernel (needs libmpcqp_timing.so, see csrc/Makefile).
-usage: MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py [workload] [batch] [variant]"""
+usage: MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py [workload] [batch] [variant|-] [horizon]"""
 import ctypes as C
 import os
 import sys
@@ -10,12 +10,13 @@ import numpy as np
 
 name = sys.argv[1] if len(sys.argv) > 1 else "quadrotor"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] != "-":
     os.environ["MPCQP_VARIANT"] = sys.argv[3]
+horizon = int(sys.argv[4]) if len(sys.argv) > 4 else None
 from optimal_control_problem_amd import _lib, models
 from optimal_control_problem_amd.batch_qp import BatchQP
 
-mdl, ls, _ = models.make_workload(name, batch)
+mdl, ls, _ = models.make_workload(name, batch, N=horizon) if horizon else models.make_workload(name, batch)
 qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
 qp.update(ls.P, ls.q, ls.A, ls.l, ls.u)
 for _ in range(2):
