@@ -197,7 +197,7 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
   const bool junc = oc.junc && LF > 0;
   const int S = junc ? max(LE + 1, LF) : LE;          // chain steps run in phases 0 .. S - 1 (chain F keeps its last step, the junction, for phase S - 1); helpers one phase behind
   const int ch = wid & 1;
-  const bool helper = wid == 2 || wid == 3, idle = wid >= 4;
+  const bool helper = NW > 4 ? (wid == 2 || wid == 3) : wid >= 2, idle = NW > 4 && wid >= 4;
   const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
   const int *pt = oc.tab + oc.o_pos;
   // block ids of the chain's steps, step i in lane i (read back with v_readlane: no memory latency inside a phase)
@@ -352,10 +352,212 @@ __device__ __forceinline__ void oc_touch(const void *base, const long bytes, con
 // at a fixed place -- the top of trip OC_POLL_TRIP, before any fetch of such a row (the host checks that: plan.hpp oc_late_chunks) -- on a
 // ticket in LDS that wave 3 sets to the iteration number once its rows are written.
 constexpr int OC_POLL_TRIP = 3;
+// (Two texts of the same solve.  oc_solve is the four-wave form exactly as it was tuned in round 2 -- chain loops unrolled for OC_MAXT trips, two
+// position groups -- and oc_solve_long, further down, the form for the eight-wave instances: chain loops of any length, any number of position
+// groups, per-solve recomputation of the LDS addresses.  The product of merging them ran 5 % slower on the north-star size: this kernel's
+// schedule does not survive a change of its text.)
 template <int NW, int NG, int NH, bool HUB, class Late, class Idle>
 __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln, const OcWave<NG> &ow,
                                          const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
                                          volatile int *ticket, const int iter, Late &&late, Idle &&idle, unsigned long long *stamp = nullptr) {
+#ifdef MPCQP_TIMING
+#define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
+  unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#else
+#define OC_TS(k) __builtin_amdgcn_sched_barrier(0)
+#endif
+  double *EXT = R + npad;                          // vector blocks behind the solve vector
+  const int LE = oc_tab(tab, 0), LF = oc_tab(tab, 1);
+  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_chainE : oc.o_chainF;
+  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_chainF + 2 * (LF - 1)) : -1;
+  const int H = oc.nbc;
+  // ---- F1
+  // Two stages per trip with the roles of the two vector register sets swapped (x -> y -> x): no copy sits between an MFMA result
+  // and the MFMAs that read it as their B operand.  The next stage's block and right-hand side are loaded while a stage multiplies;
+  // table entries are read two stages ahead.
+  if (wid < 2 && len > 0) {
+    const int nst = len - 1;                           // stages: stage k multiplies block e[k].y into position e[k + 1].x
+    // (table reads past the end are clamped to the last entry: the trip body has no branch, which keeps the compiler's wait counts exact)
+    int2 e0 = oc_pair(tab, cb), e1 = oc_pair(tab, cb + 2 * min(1, nst)), e2 = oc_pair(tab, cb + 2 * min(2, nst)), e3 = oc_pair(tab, cb + 2 * min(3, nst));
+    // (4-block MFMA: a stage is 4 dependent steps of 52 cycles, its result element goes to LDS and -- as the next stage's operand -- through ds_swizzle)
+    d4 x = oc_ldB4(R, e0.x, ln), y = x;
+    d4 a = oc_ldF4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e1.x, ln);
+    int k = 0;
+#pragma unroll
+    for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
+      if (k + 2 > nst) break;
+      if (trip == OC_POLL_TRIP && oc.at_poll >= 0) {     // the late rows of the right-hand side are in place from here on
+        while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      // stage k: t = c + block(e0.y) x -> position e1.x ; prefetch stage k + 1: block e1.y, rhs of e2.x
+      const d4 a1 = oc_ldF4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e2.x, ln);
+      const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));     // entries of the next trip
+      __builtin_amdgcn_sched_barrier(0);               // the loads above are issued before the multiplies below: a whole stage to land
+      const double r0 = oc_mv4x4(a, x, c);
+      y = oc_bc4(r0);                                  // (the hand-over first: the LDS pipe is in order, and the next stage waits for exactly this)
+      __builtin_amdgcn_sched_barrier(0);
+      oc_stB4(R, e1.x, ln, r0);
+      // stage k + 1: t = c1 + block(e1.y) y -> position e2.x ; prefetch stage k + 2: block e2.y, rhs of e3.x
+      a = oc_ldF4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e3.x, ln);
+      __builtin_amdgcn_sched_barrier(0);
+      const double r1 = oc_mv4x4(a1, y, c1);
+      x = oc_bc4(r1);
+      __builtin_amdgcn_sched_barrier(0);
+      oc_stB4(R, e2.x, ln, r1);
+      e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
+    }
+    if (k < nst) {                                     // odd stage count: one more
+      const double r0 = oc_mv4x4(a, x, c);
+      oc_stB4(R, e1.x, ln, r0);
+      x = oc_bc4(r0); e0 = e1;
+    }
+    // x = t of the chain's last position e0.x
+    if (wid == 0 && oc.junc) oc_stB4(EXT, 0, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
+  } else if (wid >= 2) {
+    late(wid);
+    if (wid == 3 && oc.at_poll >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (ln.o4 == 0) *ticket = iter;
+    }
+  }
+  bsync<NW>();
+  OC_TS(0);
+  if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
+  d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand pieces (k4 + 4 K)
+  double xhd = 0.0;           // ... and as its element of the result (o4)
+  constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
+  if (HUB) {
+    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions
+    double hsum = 0.0;
+    {
+      d4 t[NA], a[NA]; double acc[NA];
+#pragma unroll
+      for (int s = 0; s < NA; s++) { t[s] = oc_ldB4(R, ow.vpos[s], ln); a[s] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s] = 0.0; }
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(a[s][K], t[s][K], acc[s]);
+#pragma unroll
+      for (int s = 0; s < NA; s++) hsum += acc[s];
+    }
+    if (NG > NA) {
+      d4 t[NG - NA > 0 ? NG - NA : 1], a[NG - NA > 0 ? NG - NA : 1]; double acc[NG - NA > 0 ? NG - NA : 1];
+#pragma unroll
+      for (int s = NA; s < NG; s++) { t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); a[s - NA] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s - NA] = 0.0; }
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(a[s - NA][K], t[s - NA][K], acc[s - NA]);
+#pragma unroll
+      for (int s = NA; s < NG; s++) hsum += acc[s - NA];
+    }
+    oc_stB4(EXT, 1 + wid, ln, hsum);
+    bsync<NW>();
+    // ---- F3: t_hub, x_hub = G_hub t_hub on every wave; the result goes through LDS once to become an operand (every wave writes the same
+    // values to the junction block, which is free by now)
+    d4 th = oc_ldB4(R, H, ln);
+#pragma unroll
+    for (int w = 0; w < NW; w++) th += oc_ldB4(EXT, 1 + w, ln);
+    const d4 gh = oc_ldF4(BL + (long)oc.ghub_slot * BLK, ln);
+#pragma unroll
+    for (int K = 0; K < 4; K++) xhd = oc_mv4(gh[K], th[K], xhd);
+    oc_stB4(EXT, 0, ln, xhd);
+    xh = oc_ldB4(EXT, 0, ln);
+  }
+  OC_TS(1);
+  // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
+  {
+    d4 t[NA], g[NA], h[NA]; double acc[NA];
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      t[s] = oc_ldB4(R, ow.vpos[s], ln); g[s] = G[s]; acc[s] = 0.0;
+      if (HUB) h[s] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
+    }
+#pragma unroll
+    for (int K = 0; K < 4; K++)
+#pragma unroll
+      for (int s = 0; s < NA; s++) acc[s] = oc_mv4(g[s][K], t[s][K], acc[s]);
+    if (HUB) {
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(h[s][K], xh[K], acc[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NA; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s]);
+  }
+  if (NG > NA) {
+    constexpr int NB = NG - NA > 0 ? NG - NA : 1;
+    d4 t[NB], g[NB], h[NB]; double acc[NB];
+#pragma unroll
+    for (int s = NA; s < NG; s++) {
+      t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); g[s - NA] = G[s]; acc[s - NA] = 0.0;
+      if (HUB) h[s - NA] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
+    }
+#pragma unroll
+    for (int K = 0; K < 4; K++)
+#pragma unroll
+      for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(g[s - NA][K], t[s - NA][K], acc[s - NA]);
+    if (HUB) {
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(h[s - NA][K], xh[K], acc[s - NA]);
+    }
+#pragma unroll
+    for (int s = NA; s < NG; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s - NA]);
+  }
+  bsync<NW>();
+  OC_TS(2);
+  // ---- B2
+  if (HUB && wid == NW - 1) oc_stB4(R, H, ln, xhd);     // only now: every wave has read the hub's right-hand side
+  if (wid < 2 && len > 0) {
+    // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
+    int k = len - 2;
+    d4 x;
+    if (wid == 0 && oc.junc) { x = oc_ldB4(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
+    else x = oc_ldB4(R, tab[cb + 2 * (len - 1)], ln);
+    if (k >= 0) {
+      int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
+      d4 y = x;
+      d4 a = oc_ldT4(BL + (long)e0.y * BLK, ln); double c = oc_ldE4(R, e0.x, ln);
+#pragma unroll
+      for (int trip = 0; trip < OC_MAXT; trip++) {
+        if (k < 1) break;
+        const d4 a1 = oc_ldT4(BL + (long)e1.y * BLK, ln); const double c1 = oc_ldE4(R, e1.x, ln);
+        const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const double r0 = oc_mv4x4(a, x, c);
+        y = oc_bc4(r0);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stB4(R, e0.x, ln, r0);
+        a = oc_ldT4(BL + (long)e2.y * BLK, ln); c = oc_ldE4(R, e2.x, ln);
+        __builtin_amdgcn_sched_barrier(0);
+        const double r1 = oc_mv4x4(a1, y, c1);
+        x = oc_bc4(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stB4(R, e1.x, ln, r1);
+        e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
+      }
+      if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
+    }
+  } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
+  bsync<NW>();
+#undef OC_TS
+}
+template <int NW, int NG, int NH, bool HUB, class Late, class Idle>
+__device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln_, const OcWave<NG> &ow_,
+                                         const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
+                                         volatile int *ticket, const int iter, Late &&late, Idle &&idle, unsigned long long *stamp = nullptr) {
+  // The LDS addresses of a wave's positions and block slots do not change from one ADMM iteration to the next, so the compiler computes them
+  // once, outside the iteration -- and in the eight-wave instances, whose registers mostly hold resident blocks, spills them: every use then
+  // is a scratch reload with a full wait in front of an LDS read (38 per solve, ~19k cycles per iteration measured).  Their inputs are made
+  // opaque here, once per solve: the addresses are recomputed where they are used (a few VALU instructions each).
+  OcLane ln = ln_; OcWave<NG> ow = ow_;
+  asm volatile("" : "+v"(ln.f4), "+v"(ln.t4), "+v"(ln.k4), "+v"(ln.o4));
+#pragma unroll
+  for (int s = 0; s < NG; s++) asm volatile("" : "+s"(ow.vpos[s]), "+s"(ow.hslot[s]));
 #ifdef MPCQP_TIMING
 #define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -397,22 +599,10 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
       oc_stB4(R, e2.x, ln, r1);
       e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
     };
-    if constexpr (NW == 4) {
-#pragma unroll
-      for (int trip = 0; trip < OC_MAXT; trip++) {        // fully unrolled: no loop-carried register copies between an MFMA result and its readers
-        if (k + 2 > nst) break;
-        if (trip == OC_POLL_TRIP && oc.at_poll >= 0) {     // the late rows of the right-hand side are in place from here on
-          while (*ticket != iter) __builtin_amdgcn_s_sleep(1);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        trip2();
-      }
-    } else {
-      // long chains (eight-wave instances): the same trip as a loop -- the carried values are the block, the right-hand side element, the
-      // operand and four table entries, all rewritten inside the trip
+    // the trip as a loop (chains of any length): the carried values are the block, the right-hand side element, the operand and four table
+    // entries, all rewritten inside the trip
 #pragma unroll 1
-      while (k + 2 <= nst) trip2();
-    }
+    while (k + 2 <= nst) trip2();
     if (k < nst) {                                     // odd stage count: one more
       const double r0 = oc_mv4x4(a, x, c);
       oc_stB4(R, e1.x, ln, r0);
@@ -420,13 +610,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     }
     // x = t of the chain's last position e0.x
     if (wid == 0 && oc.junc) oc_stB4(EXT, 0, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
-  } else if (wid >= 2) {
-    late(wid);
-    if (wid == 3 && oc.at_poll >= 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (ln.o4 == 0) *ticket = iter;
-    }
-  }
+  } else if (wid >= 2) late(wid);
   bsync<NW>();
   OC_TS(0);
   if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
@@ -520,16 +704,8 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
         oc_stB4(R, e1.x, ln, r1);
         e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
       };
-      if constexpr (NW == 4) {
-#pragma unroll
-        for (int trip = 0; trip < OC_MAXT; trip++) {
-          if (k < 1) break;
-          trip2();
-        }
-      } else {
 #pragma unroll 1
-        while (k >= 1) trip2();
-      }
+      while (k >= 1) trip2();
       if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
     }
   } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)

@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   auto idle_touch = [&](const int w) {
     if (io.no_touch) return;
     if (w == 2) oc_touch(valA, pl.A.entries * 8, lane);
-    else if (w == 3) { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
+    else if (NW == 4 || w == 3) { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
   };
   if (ok) {
     int iter;
@@ -950,9 +950,11 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        if constexpr (NW == 4) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        else oc_solve_long<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);
 #else
-        oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
+        if constexpr (NW == 4) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
+        else oc_solve_long<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
 #endif
       } else {
 #ifdef MPCQP_TIMING
