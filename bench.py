@@ -49,6 +49,92 @@ def host_cores():
     return n
 
 
+def lib_sha16():
+    """first 16 hex digits of sha256(libmpcqp.so): the build a committed PMC figure belongs to"""
+    import hashlib
+    from optimal_control_problem_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.lib_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def committed_traffic(key):
+    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes -- only if they were taken on THIS build of the
+    library (profiles/traffic_table.json keys each entry with the library's hash); anything else is reported as null, not as a stale number"""
+    try:
+        tbl = json.load(open(os.path.join(ROOT, "profiles", "traffic_table.json")))
+    except (OSError, ValueError):
+        return None
+    e = tbl.get(key)
+    if not isinstance(e, dict) or e.get("lib_sha16") is None or e.get("lib_sha16") != lib_sha16():
+        return None
+    return e.get("hbm_bytes_per_launch")
+
+
+def one_config(workload, N, batch, seed, dev, steps=2):
+    """one warmed step of another BASELINE configuration (same step as the timed region: update + solve + get, instances in batch order)"""
+    import torch
+    from optimal_control_problem_amd import models
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    t0 = time.time()
+    mdl, ls, _ = models.make_workload(workload, batch, seed=seed, N=N)
+    t_gen = time.time() - t0
+    d = [torch.from_numpy(a).to(dev) for a in (ls.P, ls.q, ls.A, ls.l, ls.u)]
+    ox = torch.empty(batch, ls.n, dtype=torch.float64, device=dev); oy = torch.empty(batch, ls.m, dtype=torch.float64, device=dev)
+    ost = torch.empty(batch, dtype=torch.int32, device=dev); oit = torch.empty(batch, dtype=torch.int32, device=dev)
+    qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, device=dev.index)
+    qp.set_dispatch_hint(False)
+    stream = torch.cuda.current_stream().cuda_stream
+    def step():
+        qp.update(*d); qp.solve(stream); qp.get_device(x=ox, y=oy, status=ost, iters=oit)
+    step(); torch.cuda.synchronize()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(); kms.append(qp.last_kernel_ms())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pinfo = qp.plan_info()
+    abytes = algorithmic_bytes_per_solve(pinfo["nnzP_triu"], pinfo["nnzA"], ls.n, ls.m)
+    k = float(np.mean(kms))
+    out = {"workload": "%s horizon=%d batch=%d (n=%d m=%d)" % (mdl.name, N, batch, ls.n, ls.m), "value": batch / dt, "unit": "QP solves/s", "ms_per_step": dt * 1e3, "kernel_ms": k,
+           "mean_admm_iters": float(oit.float().mean()), "solved_frac": float((ost == 1).float().mean()), "variant": pinfo["variant"], "lds_bytes_per_qp": pinfo["lds_bytes"],
+           "roofline": {"bound": "hbm", "achieved": abytes * batch / (k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes * batch / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_solve": abytes, "traffic": committed_traffic("%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"]))},
+           "workload_gen_s": t_gen}
+    qp.close()
+    del d, ox, oy
+    torch.cuda.empty_cache()
+    return out
+
+
+def sqp_iteration_device(workload, N, batch, seed, dev, reps=3):
+    """the complete device-resident SQP iteration on the headline workload (SURVEY.md section 8d's metric with the producer inside the step,
+    reference SQPOptimizationSolver.cpp:137-198): mpcqp_stage_eval -> mpcqp_update -> mpcqp_solve -> mpcqp_get -> mpcqp_stage_step / merit,
+    from the seeded iterate every time, nothing crossing PCIe"""
+    import torch
+    from optimal_control_problem_amd import models
+    from optimal_control_problem_amd.sqp import DeviceSQPOptimizationSolver
+    mdl, ls, meta = models.make_workload(workload, batch, seed=seed, N=N)
+    arg = {k: torch.as_tensor(meta[k], dtype=torch.float64, device=dev) for k in ("lbx", "ubx", "lbg", "ubg", "p")}
+    x0 = torch.as_tensor(meta["x_iterate"], dtype=torch.float64, device=dev)
+    sq = DeviceSQPOptimizationSolver(mdl, {"max_iter": 1, "alpha": 0.5}, batch=batch, device=dev.index)
+    sq.qp.set_dispatch_hint(False)
+    sq.setInitialGuess(x0); sq.getOptimalSolution(arg, to_host=False); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        sq.setInitialGuess(x0); torch.cuda.synchronize()
+        t0 = time.perf_counter(); sq.getOptimalSolution(arg, to_host=False); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    dt = float(np.mean(ts))
+    out = {"value": batch / dt, "unit": "QP solves/s (one SQP iteration each, evaluation included)", "ms_per_iteration": dt * 1e3, "qp_kernel_ms": sq.qp.last_kernel_ms(),
+           "mean_admm_iters": float(sq.iters.float().mean()), "solved_frac": float((sq.status == 1).float().mean()),
+           "steps": "mpcqp_stage_eval + mpcqp_update + mpcqp_solve + mpcqp_get + mpcqp_stage_step + mpcqp_stage_merit, inputs and iterate resident in HBM, instances in batch order"}
+    sq.close()
+    torch.cuda.empty_cache()
+    return out
+
+
 def algorithmic_bytes_per_solve(nnzP_triu, nnzA, n, m, warm=False):
     """compulsory traffic with the iteration resident on-chip."""
     b = 8 * (nnzP_triu + nnzA + n + 2 * m) + 8 * (n + m) + 16
@@ -69,7 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed region only: skip the in-order, PCIe-inclusive and CPU-baseline legs (profiling runs)")
     # diagnostics (not used by the driver): force a kernel family / an exact ADMM iteration count
-    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res4", "res8", "gres4", "oc4"])
+    ap.add_argument("--variant", default=None, choices=["stream", "res1", "res2", "res4", "res8", "gres4", "gres2", "oc4", "oc8"])
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal of the N > 1 flow on a one-GPU box: all ranks use cuda:0, collectives over gloo")
     ap.add_argument("--reduced", action="store_true", help="opt-in reduced form (mpcqp_create_reduced): the parameter rows dp = 0 named as fixed; not the headline configuration")
     ap.add_argument("--force-iters", type=int, default=None, help="run exactly this many ADMM iterations (eps = 0, no adaptive rho)")
@@ -152,9 +238,14 @@ def main():
     kms_max = sharding.max_over_ranks(kms, dist)
 
     # final gather of the solutions (the only collective that touches results; outside the timed region)
+    tg = time.perf_counter()
     gathered = sharding.gather_rows(ox, dist, dst=0)
+    if dist is not None:
+        torch.cuda.synchronize()
+    tg = time.perf_counter() - tg
     if dist is not None and rank == 0:
         assert tuple(gathered.shape) == (world * batch, ls.n)
+    collective = sharding.collective_record(dist, kms, world * batch * ls.n * 8, tg * 1e3, local, args.share_gpu)
 
     if rank == 0:
         total = world * batch * args.steps
@@ -162,14 +253,8 @@ def main():
         abytes = algorithmic_bytes_per_solve(pinfo["nnzP_triu"], pinfo["nnzA"], ls.n, ls.m)
         achieved = abytes * batch / (kms * 1e-3) / 1e9
         flops_iter = 4 * pinfo["L_blocks"] * 256 + 2 * (2 * pinfo["nnzA"]) + 2 * (2 * pinfo["nnzP_triu"] - ls.n) + 12 * (ls.n + ls.m)
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if any
-        try:
-            tbl = json.load(open(os.path.join(ROOT, "profiles", "traffic_table.json")))
-            key = "%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"])
-            if key in tbl and not args.force_iters:
-                traffic = tbl[key]["hbm_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command on this same build of the library, else null
+        traffic = None if args.force_iters else committed_traffic("%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"]))
         out = {
             "metric": "QP solves/sec (batched OSQP-ADMM, N=%d)" % N, "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -189,7 +274,7 @@ def main():
                          "algorithmic_flops_per_admm_iter": flops_iter,
                          "achieved_tflops_fp64": flops_iter * (iters_sum / world) / (kms * 1e-3) / 1e12,
                          "fp64_vector_peak_tflops": FP64_VEC_PEAK_TFLOPS,
-                         "regime": ("factor on chip (LDS + registers, two workgroups per CU); A / A' values re-read from L2 / Infinity Cache / HBM every ADMM iteration" if pinfo["variant"] >= 200 else
+                         "regime": ("factor on chip (LDS + registers, %s); A / A' values re-read from L2 / Infinity Cache / HBM every ADMM iteration" % ("one workgroup of eight waves per CU" if pinfo["variant"] == 208 else "two workgroups per CU") if pinfo["variant"] >= 200 else
                                     "factor blocks and A / A' values re-streamed from HBM every ADMM iteration (occupancy beats LDS residency at this size)"
                                     if pinfo["variant"] >= 100 or pinfo["variant"] == 0 else "factor resident in LDS; A / A' values re-read from L2 / HBM every ADMM iteration")},
             "solve_stats": {"solved_frac": solved / (world * batch), "mean_admm_iters": iters_sum / (world * batch),
@@ -201,6 +286,22 @@ def main():
                                                "LDL' %d waves/QP, factor blocks streamed from HBM" % (pinfo["variant"] - 100) if pinfo["variant"] >= 100 else
                                                "resident (%d waves/QP, factor in LDS)" % pinfo["variant"])},
         }
+        if collective is not None:
+            out["collective"] = collective
+        out["lib_sha16"] = lib_sha16()
+        if world == 1 and not args.force_iters and not args.no_extras and not args.reduced and (args.workload, N, batch) == ("quadrotor", 20, 8192):
+            # the other BASELINE configurations that fit one GPU, one warmed step each, and the complete SQP iteration -- under the driver's
+            # clock, outside the timed region of `value`
+            try:
+                out["other_configs"] = {"config2_double_integrator_N20_b4096": one_config("double_integrator", 20, 4096, 1234, dev),
+                                        "config3_quadrotor_N50_b8192": one_config("quadrotor", 50, 8192, 2024, dev),
+                                        "config4_cartpole_N100_b16384_cold": one_config("cartpole", 100, 16384, 7, dev)}
+            except Exception as e:      # a failure here must not take the headline down
+                out["other_configs"] = {"error": repr(e)}
+            try:
+                out["sqp_iteration_device"] = sqp_iteration_device("quadrotor", 20, 8192, 2024, dev)
+            except Exception as e:
+                out["sqp_iteration_device"] = {"error": repr(e)}
         if world == 1 and not args.force_iters and not args.no_extras:
             # the same step with the library's default dispatch hint on: instances ordered longest-first by the previous solve's
             # ADMM iteration counts.  On this repeated batch the prediction is exact, so this is the hint's upper bound.

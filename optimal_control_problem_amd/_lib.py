@@ -40,9 +40,14 @@ class MpcqpError(RuntimeError):
 def build(force=False):
     """Compile libmpcqp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "kernels_common.hpp", "kernel_stream.hpp", "kernel_onchip.hpp", "kernel_resident.hpp", "kernels_util.hpp", "plan.hpp", "stage_eval.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
+    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "kernels_common.hpp", "kernel_stream.hpp", "kernel_onchip.hpp", "kernel_resident.hpp", "kernels_util.hpp", "reduced.hpp", "plan.hpp", "stage_eval.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
     if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B", "../libmpcqp.so"], stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+def lib_path():
+    """the library file this process loads (MPCQP_LIB overrides: timing build, A/B runs)"""
     return SO_PATH
 
 

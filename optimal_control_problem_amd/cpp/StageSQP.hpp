@@ -85,9 +85,10 @@ class StageSQP {
       if (tol_ > 0.0) {                                           // one vector of step norms back to the host per iteration
         stepMax_.resize(B);
         hip(hipMemcpy(stepMax_.data(), g_, B * sizeof(double), hipMemcpyDeviceToHost));
-        double worst = 0.0;
-        for (double v : stepMax_) if (v > worst) worst = v;
-        if (worst < tol_) break;
+        // (instances whose QP failed report a NaN step: they neither stop the loop nor keep it going; a batch without a finite step goes on)
+        double worst = 0.0; bool any = false;
+        for (double v : stepMax_) if (v == v) { any = true; if (v > worst) worst = v; }
+        if (any && worst < tol_) break;
       }
     }
     check(mpcqp_stage_merit(ocp_, batch_, p_, x_, f_, g_, nullptr), "mpcqp_stage_merit");

@@ -14,8 +14,12 @@ def shard_range(total, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+INIT_TIMEOUT_S = 180       # rendezvous + communicator set-up; a rank that cannot join ends with a one-line reason instead of hanging the job
+
+
 def init_distributed(n_gpus, backend=None):
-    """Returns (rank, world, local_rank, dist_or_None).  world == 1 needs no process group."""
+    """Returns (rank, world, local_rank, dist_or_None).  world == 1 needs no process group.  A rank that fails to join (rendezvous, RCCL
+    communicator) exits non-zero with one line on stderr; the launcher then ends its siblings."""
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world == 1 and n_gpus <= 1:
@@ -29,7 +33,17 @@ def init_distributed(n_gpus, backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        import sys
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
+            # the first collective is where a broken RCCL set-up shows (communicators are created lazily): do it here, under the timeout
+            t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(t)
+        except Exception as e:      # noqa: BLE001 -- whatever the backend raises
+            print("sharding: rank %d of %d could not join the %s group on %s:%s: %s" % (rank, world, backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                                                                                       str(e).splitlines()[0] if str(e) else type(e).__name__), file=sys.stderr, flush=True)
+            raise SystemExit(3)
     return rank, world, local, dist
 
 
@@ -64,6 +78,29 @@ def sum_over_ranks(value, dist):
     t = torch.tensor([float(value)], dtype=torch.float64, device=_dev(dist))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_values(value, dist):
+    """one float per rank, on every rank (diagnostics of a multi-rank run: per-rank kernel times, device ordinals)"""
+    if dist is None:
+        return [float(value)]
+    import torch
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=_dev(dist))
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def collective_record(dist, kernel_ms, gather_bytes, gather_ms, local_device, share_gpu=False):
+    """what the collective layer saw in a multi-rank run -- backend, ranks, per-rank kernel time and device, size and time of the final
+    gather -- so that the record of an N-GPU run answers "did RCCL see N ranks" by itself; None for a single process.  Collective call:
+    every rank must make it."""
+    if dist is None:
+        return None
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "kernel_ms_per_rank": all_values(kernel_ms, dist),
+            "devices": [int(v) for v in all_values(float(local_device), dist)], "gather_bytes": int(gather_bytes), "gather_ms": float(gather_ms),
+            "share_gpu": bool(share_gpu)}
 
 
 def gather_rows(local, dist, dst=0):
@@ -104,24 +141,56 @@ def launch_ranks(n_ranks, argv, extra_env=None):
     import subprocess
     import sys
     import time
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    timeout_s = float(os.environ.get("MPCQP_LAUNCH_TIMEOUT_S", "1500"))
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def reap(grace=5.0):
+        """end whatever is still running: terminate, then kill after a grace period"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
     rc = 0
-    alive = list(procs)
-    while alive:
-        time.sleep(0.2)
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0:
-                rc = rc or code
-                for q in alive:
-                    q.terminate()
+    try:
+        for attempt in range(3):
+            # a free port is found by bind / close, which another job may grab in between: a rank that cannot rendezvous exits with code 3
+            # within INIT_TIMEOUT_S, and the launch is retried on a new port (fresh child processes every time)
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            del procs[:]
+            for r in range(n_ranks):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                env.update(extra_env or {})
+                procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+            rc = 0
+            t_end = time.time() + timeout_s
+            alive = list(procs)
+            while alive:
+                time.sleep(0.2)
+                if time.time() > t_end:
+                    print("sharding.launch_ranks: %d rank(s) still running after %.0f s, ending them" % (len(alive), timeout_s), file=sys.stderr, flush=True)
+                    rc = rc or 124
+                    reap()
+                    break
+                for p in list(alive):
+                    code = p.poll()
+                    if code is None:
+                        continue
+                    alive.remove(p)
+                    if code != 0:
+                        rc = rc or code
+                        reap()
+                        alive = []
+                        break
+            if rc != 3:
+                break
+    finally:
+        reap()
     return rc

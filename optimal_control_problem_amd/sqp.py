@@ -103,9 +103,17 @@ class SQPOptimizationSolver:
                 print("SQP iter %d/%d  max|dx| %.3e  f[0] %.6g" % (i + 1, self.stepNum_, normDelta, self.result_["f"][0]))
                 if normDelta < 1e-6:
                     break
-            if self.sqp_tol > 0.0 and np.nanmax(self.step_max) < self.sqp_tol:
+            if self.sqp_tol > 0.0 and _all_finite_steps_below(self.step_max, self.sqp_tol):
                 break
         return {"x": self.result_["x"].copy(), "f": self.result_["f"].copy()}
+
+
+def _all_finite_steps_below(step_max, tol):
+    """the opt-in stop of both loops (and of cpp/StageSQP.hpp): every instance with a finite step moved by less than tol.  An instance
+    whose QP failed has a NaN step -- it neither stops the loop nor keeps it going -- and a batch without any finite step goes on."""
+    s = np.asarray(step_max, float)
+    fin = np.isfinite(s)
+    return bool(fin.any()) and float(s[fin].max()) < tol
 
 
 class DeviceSQPOptimizationSolver:
@@ -206,8 +214,11 @@ class DeviceSQPOptimizationSolver:
                 print("SQP iter %d/%d  max|dx| %.3e  f[0] %.6g" % (i + 1, self.stepNum_, normDelta, float(self.f[0])))
                 if normDelta < 1e-6:
                     break
-            if self.sqp_tol > 0.0 and float(torch.nan_to_num(step, nan=0.0).max()) < self.sqp_tol:   # one scalar back to the host per iteration
-                break
+            if self.sqp_tol > 0.0:   # one scalar back to the host per iteration (-1 when no instance has a finite step)
+                fin = torch.isfinite(step)
+                worst = float(torch.where(fin, step, torch.full_like(step, -1.0)).max())
+                if 0.0 <= worst < self.sqp_tol:
+                    break
         if not to_host:
             return {"x": self.x, "f": self.f}
         return {"x": self.x.cpu().numpy(), "f": self.f.cpu().numpy()}

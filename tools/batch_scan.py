@@ -1,5 +1,5 @@
 import os, sys, json, subprocess
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from optimal_control_problem_amd import models
 from optimal_control_problem_amd.batch_qp import BatchQP

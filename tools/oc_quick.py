@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MPCQP_VARIANT"] = "oc4"
 from optimal_control_problem_amd import models
 from optimal_control_problem_amd.batch_qp import BatchQP

@@ -1,6 +1,6 @@
 """Small-batch kernel time, default selection against the on-chip mode forced: python tools/small_batch_scan.py [workload:horizon ...]"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from optimal_control_problem_amd import models
 from optimal_control_problem_amd.batch_qp import BatchQP
