@@ -175,6 +175,37 @@ class CuCaQP {
               CscView{(int)A.size1(), (int)A.size2(), ac_.data(), ar_.data(), A.ptr()}, sys[3].ptr(), sys[4].ptr());
   }
   casadi::DM getSolutionAsDM() const { return casadi::DM(std::vector<double>(solution_.begin(), solution_.begin() + numOfVariables_)); }
+  // the per-member overloads (reference CuCaQP.h:38-48, CuCaQP.cpp:43-103): same checks, same messages, same bool returns.  A DM vector is
+  // read through its structural non-zeros like the reference's casadiDMToEigenVector (CuCaQP.h:139-152): entries outside the sparsity are 0.
+  bool setHessianMatrix(const casadi::DM &hessian) {
+    pc_ = toInt(hessian.sparsity().colind(), hessian.size2() + 1); pr_ = toInt(hessian.sparsity().row(), hessian.nnz());
+    return setHessianMatrix(CscView{(int)hessian.size1(), (int)hessian.size2(), pc_.data(), pr_.data(), hessian.ptr()});
+  }
+  bool setLinearConstraintsMatrix(const casadi::DM &A) {
+    ac_ = toInt(A.sparsity().colind(), A.size2() + 1); ar_ = toInt(A.sparsity().row(), A.nnz());
+    return setLinearConstraintsMatrix(CscView{(int)A.size1(), (int)A.size2(), ac_.data(), ar_.data(), A.ptr()});
+  }
+  bool setGradient(const casadi::DM &q) { const std::vector<double> v = denseColumn(q); return setGradient(v.data(), (int)v.size()); }
+  bool setLowerBound(const casadi::DM &l) { const std::vector<double> v = denseColumn(l); return setLowerBound(v.data(), (int)v.size()); }
+  bool setUpperBound(const casadi::DM &u) { const std::vector<double> v = denseColumn(u); return setUpperBound(v.data(), (int)v.size()); }
+  // ... and the DM forms of the update members the reference declares private (CuCaQP.h:93-101)
+  bool updateHessianMatrix(const casadi::DM &hessian) {
+    pc_ = toInt(hessian.sparsity().colind(), hessian.size2() + 1); pr_ = toInt(hessian.sparsity().row(), hessian.nnz());
+    return updateHessianMatrix(CscView{(int)hessian.size1(), (int)hessian.size2(), pc_.data(), pr_.data(), hessian.ptr()});
+  }
+  bool updateLinearConstraintsMatrix(const casadi::DM &A) {
+    ac_ = toInt(A.sparsity().colind(), A.size2() + 1); ar_ = toInt(A.sparsity().row(), A.nnz());
+    return updateLinearConstraintsMatrix(CscView{(int)A.size1(), (int)A.size2(), ac_.data(), ar_.data(), A.ptr()});
+  }
+  bool updateGradient(const casadi::DM &q) { const std::vector<double> v = denseColumn(q); return updateGradient(v.data(), (int)v.size()); }
+  bool updateLowerBound(const casadi::DM &l) { const std::vector<double> v = denseColumn(l); return updateLowerBound(v.data(), (int)v.size()); }
+  bool updateUpperBound(const casadi::DM &u) { const std::vector<double> v = denseColumn(u); return updateUpperBound(v.data(), (int)v.size()); }
+  static std::vector<double> denseColumn(const casadi::DM &v) {      // (one instance: the CasADi seam is the batch = 1 drop-in)
+    std::vector<double> d((size_t)(v.size1() * v.size2()), 0.0);
+    const casadi_int *cp = v.sparsity().colind(), *ri = v.sparsity().row();
+    for (casadi_int j = 0; j < v.size2(); j++) for (casadi_int k = cp[j]; k < cp[j + 1]; k++) d[(size_t)(j * v.size1() + ri[k])] = v.ptr()[k];
+    return d;
+  }
 #endif
 
  private:

@@ -82,6 +82,41 @@ class StageCost(Expr):
         self.size = 1
 
 
+class General(Expr):
+    """fn(X, p) over the WHOLE decision vector X (horizon x frameSize, reference OCPConfig.cpp:29-46) and the parameter vector p: any
+    expression the stage pattern does not cover -- terms coupling frames that are not neighbours, different functions per frame, terms
+    in the parameters.  A NumPy callable on 1-D arrays returning `size` values (one for addScalarCost); it is traced, so it must be
+    straight-line code, like a CasADi SX expression (reference src/OptimalControlProblem.cpp:444-497 takes any SX)."""
+
+    def __init__(self, fn, size=1):
+        self.fn, self.size = fn, int(size)
+
+
+def evaluate_expression(e, X, p):
+    """value of a facade expression at decision vector X and parameters p (NumPy arrays or tracers): what the reference's SX graph of the
+    same expression evaluates to"""
+    if isinstance(e, tuple) and e[0] == "weighted_square":          # addVectorCost: sum_i param_i * cost_i^2 (reference :574-600)
+        v = evaluate_expression(e[2], X, p)
+        return sum(float(w) * (v[i] * v[i]) for i, w in enumerate(e[1]))
+    if isinstance(e, Var):
+        return X[e.start:e.stop]
+    if isinstance(e, Reference):
+        return p
+    if isinstance(e, Diff):
+        return evaluate_expression(e.a, X, p) - evaluate_expression(e.b, X, p)
+    if isinstance(e, Dynamics):
+        return e.F(evaluate_expression(e.state, X, p), evaluate_expression(e.inp, X, p))
+    if isinstance(e, Path):
+        return e.h(evaluate_expression(e.state, X, p), evaluate_expression(e.inp, X, p))
+    if isinstance(e, Link):
+        return e.k(evaluate_expression(e.state, X, p), evaluate_expression(e.inp, X, p), evaluate_expression(e.state_next, X, p), evaluate_expression(e.inp_next, X, p))
+    if isinstance(e, StageCost):
+        return e.l(evaluate_expression(e.state, X, p), evaluate_expression(e.inp, X, p), evaluate_expression(e.reference, X, p))
+    if isinstance(e, General):
+        return e.fn(X, p)
+    raise TypeError("not a facade expression: %r" % (e,))
+
+
 # ---------------------------------------------------------------------------------------------------- OCPConfig
 def _bound_value(v):
     """'.inf' / '-.inf' strings as the reference handles them (OCPConfig.cpp:152-159); PyYAML already yields floats"""
@@ -163,6 +198,19 @@ class OCPConfig:
 
     def getInitialGuess(self):
         return self.initialGuess_
+
+
+def _as_scalar(v):
+    """a cost term must be one value (a vector-valued expression of size 1 counts)"""
+    if hasattr(v, "items") and not isinstance(v, dict):
+        if len(v.items) != 1:
+            raise ValueError("a scalar cost term evaluated to %d values" % len(v.items))
+        return v.items[0]
+    if isinstance(v, np.ndarray):
+        if v.size != 1:
+            raise ValueError("a scalar cost term evaluated to %d values" % v.size)
+        return v.reshape(-1)[0]
+    return v
 
 
 # ---------------------------------------------------------------------------------------------------- OptimalControlProblem
@@ -308,13 +356,40 @@ class OptimalControlProblem:
         if self.solverType != "CUDA_SQP":
             raise NotImplementedError("solve_method %s relies on third-party NLP solvers (IPOPT / qpOASES) and is out of scope; "
                                       "use CUDA_SQP" % self.solverType)
-        self.model_ = self._compile_stage_model()
+        # the stage pattern compiles to the batched evaluator (host or device); anything else -- terms coupling frames that are not
+        # neighbours, different functions per frame, arbitrary expressions over the whole decision vector -- takes the general path: f and g
+        # traced and differentiated over the whole vector on the host (general_nlp.GeneralNLP), the QPs solved on the GPU all the same.
+        # The reference handles every problem that way (src/OptimalControlProblem.cpp:235-240, SQPOptimizationSolver.cpp:47-77).
+        self.generalPath_ = False
+        try:
+            self.model_ = self._compile_stage_model()
+        except NotImplementedError as why:
+            self.model_ = self._compile_general_model()
+            self.generalPath_, self.generalPathReason_ = True, str(why)
+            if self.solverSettings["verbose"]:
+                print("OptimalControlProblem: not a stage pattern (%s); general host evaluation, QPs on the GPU" % why)
         options = {"max_iter": self.solverSettings["stepNum"], "alpha": self.solverSettings["alpha"],
                    "verbose": self.solverSettings["verbose"]}
-        if self.deviceResident and self._qp_solver is None:
+        if self.deviceResident and self._qp_solver is None and not self.generalPath_:
             self.OSQPSolverPtr_ = DeviceSQPOptimizationSolver(self.model_, options, batch=self.batch)
         else:
             self.OSQPSolverPtr_ = SQPOptimizationSolver(self.model_, options, batch=self.batch, qp_solver=self._qp_solver)
+
+    def _compile_general_model(self):
+        """f = sum of the cost terms, g = the constraints in the order they were added, over w = [reference; X] (the reference's
+        {x, f, g, p}, src/OptimalControlProblem.cpp:235-240)"""
+        from .general_nlp import GeneralNLP
+        cfg = self.OCPConfigPtr_
+        nvar = cfg.getVariables(); npar = self.reference_.size if self.reference_ is not None else 0
+        if not self.costs_:
+            raise RuntimeError("Cost function is empty")
+        cost = lambda w: sum(_as_scalar(evaluate_expression(c, w[npar:], w[:npar])) for c in self.costs_)
+        cons = lambda w: [evaluate_expression(c, w[npar:], w[:npar]) for c in self.constraints_]
+        model = GeneralNLP(nvar, npar, cost, cons)
+        if model.ng != sum(len(b) for b in self.constraintLowerBounds_):
+            raise ValueError("SX used for constraints has different dimension!")
+        self._row_order = list(range(len(self.constraints_)))
+        return model
 
     def _compile_stage_model(self):
         cfg = self.OCPConfigPtr_

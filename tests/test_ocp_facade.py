@@ -196,3 +196,146 @@ def test_ocp_module_snake_case_surface(built):
     assert os.path.exists(lib) and lib.endswith(".so")
     with pytest.raises(NotImplementedError):
         ocp_module.OptimalControlProblem(_node()).deploy_constraints_and_add_cost()
+
+
+# ---------------------------------------------------------------------------------------------- general (slow) path
+# Anything the stage pattern does not cover -- the reference accepts arbitrary SX over the whole decision vector
+# (src/OptimalControlProblem.cpp:444-497) -- is evaluated on the host over the whole vector (general_nlp.GeneralNLP) and its QPs are
+# solved by the same engine.
+from optimal_control_problem_amd.ocp import General  # noqa: E402
+
+TESTCPP_YAML = """
+optimal_control_problem:
+  discretization_settings: {dt: 0.1, horizon: 2}
+  solver_settings:
+    verbose: false
+    gen_code: false
+    load_lib: false
+    max_iter: 1000
+    warm_start: true
+    solve_method: CUDA_SQP
+    SQP_settings: {alpha: 1.0, step_num: 10}
+  OCP_variables:
+    - name: "x"
+      size: %d
+      lower_bound: %s
+      upper_bound: %s
+"""
+
+
+def _fmt(b):
+    return "[" + ", ".join(".inf" if v == np.inf else "-.inf" if v == -np.inf else repr(float(v)) for v in b) + "]"
+
+
+def _testcpp_through_builders(idx, qp_solver=None, batch=1):
+    """the NLPs of the reference's test/test.cpp:13-185 (cases 1-7) stated through the OptimalControlProblem builders: the decision
+    variables are frame 1 of a two-frame problem (frame 0 is pinned by computeOptimalTrajectory, reference :93-96, and appears nowhere),
+    cost and constraints are General expressions, case 6's parameter is the reference vector.  Returns (solution of frame 1, expected)."""
+    mdl, arg, expect = models.reference_test_cases()[idx]
+    nx, npar = mdl.nx, mdl.np
+
+    class Problem(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            self.setReference(max(npar, 1))
+            w_of = lambda X, p: [p[i] for i in range(npar)] + [X[nx + i] for i in range(nx)]           # the case's w = [p; x], x = frame 1
+            if idx == 5:
+                self.addScalarCost(General(lambda X, p: (X[nx] - p[0]) ** 2 + X[nx + 1] ** 2))
+            else:
+                c = {0: [0, 0], 1: [3, -2], 2: [2, 3], 3: [0, 0], 4: [1, 2, 3], 6: [3, 4]}[idx]
+                self.addScalarCost(General(lambda X, p: sum((X[nx + i] - float(c[i])) ** 2 for i in range(nx))))
+            lbg, ubg = np.asarray(arg["lbg"], float), np.asarray(arg["ubg"], float)
+            if idx in (0, 2):
+                self.addInequalityConstraint("sum", lbg, General(lambda X, p: [X[nx] + X[nx + 1] - 1.0], 1), ubg)
+            elif idx == 3:
+                self.addInequalityConstraint("each", lbg, General(lambda X, p: [X[nx], X[nx + 1]], 2), ubg)
+            elif idx == 4:
+                self.addInequalityConstraint("sum", lbg, General(lambda X, p: [X[nx] + X[nx + 1] + X[nx + 2] - 5.0], 1), ubg)
+            else:       # the reference refuses a problem without constraints ("Constraints are empty", :231-233): a loose row
+                self.addInequalityConstraint("none", [-np.inf], General(lambda X, p: [X[nx]], 1), [np.inf])
+
+    node = yaml.safe_load(TESTCPP_YAML % (nx, _fmt(arg["lbx"]), _fmt(arg["ubx"])))["optimal_control_problem"]
+    ocp = Problem(node, batch=batch, qp_solver=qp_solver)
+    ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    assert ocp.generalPath_
+    p = np.asarray(arg["p"], float) if npar else np.zeros(1)
+    x = ocp.computeOptimalTrajectory(np.zeros((batch, nx)), np.tile(p, (batch, 1)))
+    return x[:, nx:], np.asarray(expect, float)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_general_path_testcpp_cases_with_oracle_backend(built, idx):
+    from tests.support.oracle_backend import OracleCuCaQP
+    x, expect = _testcpp_through_builders(idx, qp_solver=OracleCuCaQP(batch=1))
+    assert np.abs(x[0] - expect).max() < 5e-3, (x, expect)
+
+
+class SkipCoupledOCP(DoubleIntegratorOCP):
+    """the double-integrator OCP plus a constraint between frames k and k + 2 -- |u_{k+2} - u_k| <= d: not a stage pattern
+    (frames further apart than neighbours), so genSolver() takes the general path"""
+    d = 0.05
+
+    def deployConstraintsAndAddCost(self):
+        super().deployConstraintsAndAddCost()
+        cfg = self.OCPConfigPtr_
+        for k in range(cfg.getHorizon() - 2):
+            self.addInequalityConstraint("skip", [-self.d], cfg.getVariable(k + 2, "input") - cfg.getVariable(k, "input"), [self.d])
+
+
+def _skip_node():
+    node = _node()
+    node["discretization_settings"]["dt"] = 0.05; node["discretization_settings"]["horizon"] = 10
+    return node
+
+
+def test_general_path_constraint_coupling_frames_k_and_k_plus_2(built):
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 3
+    ocp = SkipCoupledOCP(_skip_node(), batch=B, qp_solver=OracleCuCaQP(batch=B))
+    ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    assert ocp.generalPath_ and "dynamics defects" in ocp.generalPathReason_
+    m = ocp.model_
+    assert (m.n, m.ng) == (2 + 30, 18 + 8)
+    # exact structure, not dense: a dynamics row touches its two frames, a skip row two inputs; the Hessian is diagonal in X plus the p coupling
+    jm = m.am[m.n:]
+    assert jm[:18].sum(axis=1).max() <= 4 and (jm[18:].sum(axis=1) == 2).all()
+    assert m.hm.sum() == 2 + 20 + 2 * 20 + 10          # p block diagonal, state diagonals, state-p couplings, input diagonals
+    frame = np.array([[1.0, 0.0, 0.0], [0.5, -0.2, 0.0], [-1.0, 0.3, 0.0]]); ref = np.zeros((B, 2))
+    x = ocp.computeOptimalTrajectory(frame, ref).reshape(B, 10, 3)
+    assert np.abs(x[:, 0] - frame).max() < 2e-3
+    du2 = x[:, 2:, 2] - x[:, :-2, 2]
+    assert du2.max() <= SkipCoupledOCP.d + 5e-3 and du2.min() >= -SkipCoupledOCP.d - 5e-3
+    assert np.abs(du2).max() > 0.5 * SkipCoupledOCP.d                  # the constraint binds
+    # the same problem without the skip rows is the stage pattern: the general path on IT must agree with the compiled stage model
+    plain = DoubleIntegratorOCP(_skip_node(), batch=B, qp_solver=OracleCuCaQP(batch=B))
+    plain.deployConstraintsAndAddCost(); plain.genSolver()
+    assert not plain.generalPath_
+    forced = DoubleIntegratorOCP(_skip_node(), batch=B, qp_solver=OracleCuCaQP(batch=B))
+    forced.deployConstraintsAndAddCost(); forced._compile_stage_model = lambda: (_ for _ in ()).throw(NotImplementedError("forced"))
+    forced.genSolver()
+    assert forced.generalPath_
+    xa = plain.computeOptimalTrajectory(frame, ref); xb = forced.computeOptimalTrajectory(frame, ref)
+    assert np.abs(xa - xb).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(7))
+def test_general_path_testcpp_cases_on_gpu(built, idx):
+    """the same seven NLPs through the builders with the real engine, against the oracle-backed run"""
+    from tests.support.oracle_backend import OracleCuCaQP
+    xg, expect = _testcpp_through_builders(idx)
+    xo, _ = _testcpp_through_builders(idx, qp_solver=OracleCuCaQP(batch=1))
+    assert np.abs(xg[0] - expect).max() < 5e-3 and np.abs(xg - xo).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_general_path_skip_coupling_on_gpu(built):
+    from tests.support.oracle_backend import OracleCuCaQP
+    B = 4
+    frame = np.array([[1.0, 0.0, 0.0], [0.5, -0.2, 0.0], [-1.0, 0.3, 0.0], [0.2, 0.1, 0.0]]); ref = np.zeros((B, 2))
+    out = []
+    for qp in (None, OracleCuCaQP(batch=B)):
+        ocp = SkipCoupledOCP(_skip_node(), batch=B, qp_solver=qp)
+        ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+        assert ocp.generalPath_
+        out.append(ocp.computeOptimalTrajectory(frame, ref))
+    assert np.abs(out[0] - out[1]).max() < 1e-6
