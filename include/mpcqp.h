@@ -76,6 +76,18 @@ int mpcqp_create(int n, int m, int batch,
                  const int *A_colptr, const int *A_rowidx,
                  const mpcqp_settings *settings, mpcqp_handle **out);
 
+/* Opt-in: mpcqp_create with the kernel family chosen by MEASUREMENT instead of by the rules tuned on the MPC workloads (for patterns those
+ * rules have never seen).  Every family that takes the pattern and size (the rule's own choice, the on-chip modes, the LDS-resident and the
+ * global-block kernels) gets a handle, runs a synthetic QP on this pattern (unit diagonal P, pseudo-random A, box around the origin, a fixed
+ * number of ADMM iterations), and the fastest one is returned; the others are destroyed.  The handle that comes back IS a handle of that
+ * family: results are bitwise what MPCQP_VARIANT=<family> gives.  The choice is cached per (pattern, batch) for the life of the process.
+ * Costs a few hundred milliseconds at create -- the pattern-dependent part of what the reference pays in initSolver for every QP
+ * (CuCaQP.cpp:183-197).  The environment variable MPCQP_AUTOTUNE=1 makes mpcqp_create behave like this entry point; default: off. */
+int mpcqp_create_tuned(int n, int m, int batch,
+                       const int *P_colptr, const int *P_rowidx,
+                       const int *A_colptr, const int *A_rowidx,
+                       const mpcqp_settings *settings, mpcqp_handle **out);
+
 /* Opt-in reduced form.  The reference's QP carries variables that are fixed by construction: the parameter block p, whose rows
  * read p <= p + dp <= p (SQPOptimizationSolver.cpp:47-60,117), and the first frame, pinned through lbx = ubx
  * (src/OptimalControlProblem.cpp:93-96).  OSQP iterates on them like on any other variable, and so does a handle from

@@ -41,9 +41,10 @@ def _ptr_stride(a, width, batch, name):
 
 
 class BatchQP:
-    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, fixed_rows=None, **kw):
+    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, fixed_rows=None, tuned=False, **kw):
         """fixed_rows: opt-in reduced form (mpcqp_create_reduced) -- singleton rows of A with l = u in every instance, whose
-        variables are substituted before the solve; None (default) = the full form, what the reference's OSQP solves"""
+        variables are substituted before the solve; None (default) = the full form, what the reference's OSQP solves.
+        tuned: opt-in mpcqp_create_tuned -- the kernel family chosen by measurement on this pattern instead of by rule"""
         self.n, self.m, self.batch = int(n), int(m), int(batch)
         self.Pp = np.ascontiguousarray(Pp, dtype=np.int32); self.Pi = np.ascontiguousarray(Pi, dtype=np.int32)
         self.Ap = np.ascontiguousarray(Ap, dtype=np.int32); self.Ai = np.ascontiguousarray(Ai, dtype=np.int32)
@@ -54,7 +55,7 @@ class BatchQP:
         self._keep = []
         L = _lib.lib()
         if fixed_rows is None:
-            _lib.check(L.mpcqp_create(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
+            _lib.check((L.mpcqp_create_tuned if tuned else L.mpcqp_create)(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
                                       self.Ap.ctypes.data, self.Ai.ctypes.data, C.byref(self.settings), C.byref(self._h)))
         else:
             fr = np.ascontiguousarray(fixed_rows, dtype=np.int32)

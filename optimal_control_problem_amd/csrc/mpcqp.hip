@@ -49,6 +49,8 @@ using namespace mpcqp;
 
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_last_error;
+static thread_local const char *g_force_variant = nullptr;      // mpcqp_create_tuned: the family the next mpcqp_create on this thread must take ("" = the rule's choice)
+static const char *variant_request() { return g_force_variant ? (g_force_variant[0] ? g_force_variant : nullptr) : getenv("MPCQP_VARIANT"); }
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 int mpcqp_set_error(int code, const std::string &msg) { return fail(code, msg); }
 int mpcqp_pick_device(int requested, int *device) {
@@ -195,6 +197,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   if (!out) return fail(MPCQP_ERR_ARG, "out is null");
   *out = nullptr;
   if (n <= 0 || m < 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  if (!g_force_variant && !getenv("MPCQP_VARIANT") && getenv("MPCQP_AUTOTUNE") && getenv("MPCQP_AUTOTUNE")[0] == '1')
+    return mpcqp_create_tuned(n, m, batch, Pp, Pi, Ap, Ai, settings, out);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MPCQP_ERR_NO_GPU, "hipGetDeviceCount found no device");
   mpcqp_handle *h = new mpcqp_handle();
@@ -220,7 +224,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   {
     const long LDS_MAX = 160 * 1024;
     int want = -1;
-    if (const char *e = getenv("MPCQP_VARIANT")) {
+    if (const char *e = variant_request()) {
       std::string v(e);
       if (v == "stream") want = 0; else if (v == "res1") want = 1; else if (v == "res4") want = 4; else if (v == "res8") want = 8;
       else if (v == "gres4") { want = 4; h->gblocks = true; }
@@ -296,7 +300,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     }
     // Long chains: where the rules above arrive at a factor streamed from the slab, the eight-wave on-chip instances take the pattern if it is
     // a block chain with an arrow head of up to 56 blocks that fits one CU (MPCQP_NO_OC8 keeps the global-block kernels)
-    if ((h->oc8 < 0 || (want > 0 && h->gblocks && !h->oc && !getenv("MPCQP_VARIANT") && !getenv("MPCQP_NO_OC8") && !getenv("MPCQP_NO_OC"))) && small_ok) {
+    if ((h->oc8 < 0 || (want > 0 && h->gblocks && !h->oc && !variant_request() && !getenv("MPCQP_NO_OC8") && !getenv("MPCQP_NO_OC"))) && small_ok) {
       Plan p8 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 3 : -1, 2);
       h->oc8 = 0;
       if (p8.error.empty()) {
@@ -308,7 +312,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
           }
         }
       }
-      if (!h->oc8 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc8")
+      if (!h->oc8 && variant_request() && std::string(variant_request()) == "oc8")
         return bail(fail(MPCQP_ERR_LIMIT, "the eight-wave on-chip variant does not take this pattern / size"));
     }
     if (h->oc && !h->oc8) {
@@ -321,14 +325,14 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         // same ordering and blocks, ELL widths for this instance's 8 slots in flight (plan.hpp build_ell pad = 2)
         if (!getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
       }
-      if (!h->oc && want == 4 && getenv("MPCQP_VARIANT") && std::string(getenv("MPCQP_VARIANT")) == "oc4")
+      if (!h->oc && want == 4 && variant_request() && std::string(variant_request()) == "oc4")
         return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));
     }
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want, h->gblocks && !h->oc);
       long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
-      if (h->gblocks && !h->oc && !getenv("MPCQP_NO_ZYG")) {
+      if (h->gblocks && !h->oc && want == 4 && !getenv("MPCQP_NO_ZYG")) {     // (the two-wave global-block kernel has no such instance: forced on a long horizon it took this layout and returned garbage)
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
         const long alt = lds_bytes_res_gb(pl, h->rplan, true);
         const long fit = LDS_MAX / need, fit_alt = std::min<long>(LDS_MAX / alt, 3);
@@ -428,6 +432,85 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   *out = h;
   return MPCQP_OK;
+}
+
+// ---- kernel family by measurement (include/mpcqp.h mpcqp_create_tuned)
+static std::mutex g_tune_mu;
+static std::map<std::string, std::string> g_tune_cache;     // pattern + batch + device -> family
+static std::string tune_key(int n, int m, int batch, int dev, const int *Pp, const int *Pi, const int *Ap, const int *Ai) {
+  unsigned long long hsh = 1469598103934665603ULL;          // FNV-1a over the index arrays
+  auto mix = [&](const int *p, long cnt) { for (long k = 0; k < cnt; k++) { hsh ^= (unsigned)p[k]; hsh *= 1099511628211ULL; } };
+  mix(Pp, n + 1); mix(Pi, Pp[n]); mix(Ap, n + 1); mix(Ai, Ap[n]);
+  return std::to_string(n) + "x" + std::to_string(m) + "x" + std::to_string(batch) + "@" + std::to_string(dev) + ":" + std::to_string(hsh);
+}
+int mpcqp_create_tuned(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                       const mpcqp_settings *settings, mpcqp_handle **out) {
+  if (!out) return fail(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n <= 0 || m < 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  for (int j = 0; j < n; j++) if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) return fail(MPCQP_ERR_ARG, "colptr not monotone");
+  struct Force { const char *prev; explicit Force(const char *v) : prev(g_force_variant) { g_force_variant = v; } ~Force() { g_force_variant = prev; } };
+  mpcqp_settings st; if (settings) st = *settings; else mpcqp_default_settings(&st);
+  int dev = st.device; if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const std::string key = tune_key(n, m, batch, dev, Pp, Pi, Ap, Ai);
+  {
+    std::string cached;
+    { std::lock_guard<std::mutex> lock(g_tune_mu); auto it = g_tune_cache.find(key); if (it != g_tune_cache.end()) cached = it->second; }
+    if (!cached.empty()) { Force f(cached == "rule" ? "" : cached.c_str()); return mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out); }
+  }
+  // the synthetic QP on this pattern: P = unit diagonal (other entries 0: positive semidefinite whatever the pattern), A pseudo-random in
+  // [-1, 1], q pseudo-random, -1 <= A x <= 1 (feasible at the origin); one instance shared by the batch (stride 0)
+  const long nnzP = Pp[n], nnzA = Ap[n];
+  std::vector<double> Pv(std::max<long>(nnzP, 1), 0.0), Av(std::max<long>(nnzA, 1), 0.0), qv(n), lv(std::max(m, 1), -1.0), uv(std::max(m, 1), 1.0);
+  unsigned long long seed = 88172645463325252ULL;
+  auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (double)(seed >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
+  for (int j = 0; j < n; j++) for (int k = Pp[j]; k < Pp[j + 1]; k++) if (Pi[k] == j) Pv[k] = 1.0;
+  for (long k = 0; k < nnzA; k++) Av[k] = rnd();
+  for (int j = 0; j < n; j++) qv[j] = rnd();
+  // fixed work: set-up + TUNE_ITERS ADMM iterations, no early exit (eps = 0), no adaptive rho -- what a typical MPC solve costs (25 - 50 iterations)
+  mpcqp_settings ts = st;
+  ts.max_iter = 50; ts.eps_abs = ts.eps_rel = 0.0; ts.eps_prim_inf = ts.eps_dual_inf = 0.0; ts.adaptive_rho = 0; ts.warm_start = 0;
+  const char *families[] = {"", "oc4", "oc8", "gres4", "gres2", "res4", "res2", "res1"};
+  mpcqp_handle *best = nullptr; float best_ms = 0.f; std::string best_family; long seen_codes[8]; int nseen = 0;
+  std::vector<double> xref;
+  int last_rc = MPCQP_ERR_LIMIT;
+  for (const char *fam : families) {
+    mpcqp_handle *h = nullptr;
+    int rc;
+    { Force f(fam); rc = mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, &ts, &h); }
+    if (rc != MPCQP_OK) { if (rc != MPCQP_ERR_LIMIT) last_rc = rc; continue; }
+    long info[16]; mpcqp_plan_info(h, info);
+    const long code = info[15] * 1000000 + info[7];                 // family + LDS footprint: the same kernel instance is timed once
+    bool dup = false; for (int k = 0; k < nseen; k++) dup |= seen_codes[k] == code;
+    if (dup) { mpcqp_destroy(h); continue; }
+    seen_codes[nseen++] = code;
+    float ms = 0.f; bool ok = true;
+    mpcqp_set_dispatch_hint(h, 0);
+    ok = mpcqp_update(h, Pv.data(), 0, qv.data(), 0, Av.data(), 0, lv.data(), 0, uv.data(), 0, MPCQP_MEM_HOST) == MPCQP_OK;
+    for (int rep = 0; rep < 2 && ok; rep++) ok = mpcqp_solve(h, nullptr) == MPCQP_OK && mpcqp_last_kernel_ms(h, &ms) == MPCQP_OK;     // (the first launch warms the code object)
+    // a candidate only counts if it did the work: every instance ran the full iteration count, and its x agrees with the first
+    // candidate's (the families are the same algorithm: the first and the last instance of the batch are compared to 1e-6)
+    if (ok) {
+      std::vector<int> stt(batch), itr(batch); std::vector<double> xs((size_t)batch * n);
+      ok = mpcqp_get(h, xs.data(), nullptr, nullptr, stt.data(), itr.data(), nullptr, MPCQP_MEM_HOST) == MPCQP_OK;
+      for (int b = 0; b < batch && ok; b++) ok = itr[b] == ts.max_iter && (stt[b] == MPCQP_MAX_ITER_REACHED || stt[b] == MPCQP_SOLVED || stt[b] == MPCQP_SOLVED_INACCURATE);
+      if (ok) {
+        std::vector<double> x0(xs.begin(), xs.begin() + n), x1(xs.end() - n, xs.end());
+        if (xref.empty()) xref = x0;
+        double scale = 1.0, err = 0.0;
+        for (int j = 0; j < n; j++) { scale = std::max(scale, std::fabs(xref[j])); err = std::max(err, std::max(std::fabs(x0[j] - xref[j]), std::fabs(x1[j] - xref[j]))); }
+        ok = err == err && err <= 1e-6 * scale;
+      }
+    }
+    if (!ok) { mpcqp_destroy(h); continue; }
+    if (!best || ms < best_ms) { if (best) mpcqp_destroy(best); best = h; best_ms = ms; best_family = fam[0] ? fam : "rule"; }
+    else mpcqp_destroy(h);
+  }
+  if (!best) return last_rc == MPCQP_ERR_LIMIT ? fail(MPCQP_ERR_LIMIT, "no kernel family takes this pattern / size") : last_rc;
+  mpcqp_destroy(best);       // (its settings were the tuning run's: the handle that is returned is created afresh with the caller's)
+  { std::lock_guard<std::mutex> lock(g_tune_mu); g_tune_cache[key] = best_family; }
+  Force f(best_family == "rule" ? "" : best_family.c_str());
+  return mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out);
 }
 
 int mpcqp_create_reduced(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,

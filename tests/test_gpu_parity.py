@@ -907,3 +907,52 @@ def test_reduced_form_refuses_what_it_must(built):
     qp.update(ls.P, ls.q, ls.A, l, ls.u); qp.solve(); got = qp.get()
     assert got["status"][2] == 11 and np.isnan(got["x"][2]).all() and (np.delete(got["status"], 2) == 1).all()
     qp.close()
+
+
+# ---------------------------------------------------------------------------------------------- kernel family by measurement
+@pytest.mark.parametrize("name,N,B", [("double_integrator", 20, 512), ("quadrotor", 10, 256), ("cartpole", 30, 256)])
+def test_tuned_create_returns_a_family_handle(built, monkeypatch, name, N, B):
+    """mpcqp_create_tuned (opt-in; MPCQP_AUTOTUNE=1 routes mpcqp_create to it): the handle that comes back is a handle of one family --
+    results bitwise those of MPCQP_VARIANT=<that family> -- the choice is cached per pattern, and the default create is untouched"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    names = {1: "res1", 2: "res2", 4: "res4", 102: "gres2", 104: "gres4", 204: "oc4", 208: "oc8"}
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+
+    def run(**kw):
+        qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, **kw)
+        v = qp.plan_info()["variant"]
+        qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+        return v, got
+
+    v_rule, g_rule = run()
+    v_tuned, g_tuned = run(tuned=True)
+    assert v_tuned in names
+    monkeypatch.setenv("MPCQP_VARIANT", names[v_tuned])
+    v_forced, g_forced = run()
+    monkeypatch.delenv("MPCQP_VARIANT")
+    assert v_forced == v_tuned
+    for k in ("x", "y", "z", "status", "iters"):
+        assert np.array_equal(g_tuned[k], g_forced[k], equal_nan=True), k
+    monkeypatch.setenv("MPCQP_AUTOTUNE", "1")                     # the environment switch takes the same (cached) choice
+    v_env, g_env = run()
+    monkeypatch.delenv("MPCQP_AUTOTUNE")
+    assert v_env == v_tuned and np.array_equal(g_env["x"], g_tuned["x"], equal_nan=True)
+    assert run()[0] == v_rule                                     # default behaviour unchanged
+    ref = problems.oracle_solve(ls)
+    assert (g_tuned["status"] == ref["status"]).all() and (g_tuned["iters"] == ref["iters"]).all()
+    _close(g_tuned, ref, "x")
+
+
+def test_two_wave_global_block_kernel_on_a_long_horizon(built, monkeypatch):
+    """MPCQP_VARIANT=gres2 forced on a horizon for which the four-wave global-block kernel moves z, y into the slab: the two-wave kernel
+    has no such instance and must keep them in LDS (it once took the other layout and reported every QP non-convex)"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VARIANT", "gres2")
+    mdl, ls, _ = models.make_workload("quadrotor", 8, N=50)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert qp.plan_info()["variant"] == 102
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
