@@ -181,9 +181,10 @@ const char *mpcqp_strerror(int code);            /* replaces the std::cerr messa
  * recorded around the launch on its stream (waits for the kernel). */
 int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms);
 /* info[0..15]: n, m, batch, npad, mpad, n_blocks(n/16), L_blocks, lds_bytes_per_qp, workspace_bytes_per_qp,
- * ordering(0 natural,1 hubs-last), nnzP_triu, nnzA, T_blocks, factor_ops, ell_slots_total,
+ * ordering(0 natural,1 hubs-last,2 twisted), nnzP_triu, nnzA, T_blocks, factor_ops (on-chip kernels: the number of dense 16 x 16 tiles of A the
+ * iteration's two sweeps run on, 0 = ELL only), ell_slots_total,
  * variant (0 = streaming kernel, NW > 0 = LDS-resident factor with NW waves per QP, 100 + NW = same kernels with
- * the factor blocks left in the HBM slab) */
+ * the factor blocks left in the HBM slab, 200 + NW = on-chip mode: factor in LDS + registers) */
 int mpcqp_plan_info(const mpcqp_handle *h, long *info16);
 
 /* Replaces CuCaQP::printSolverData (CuCaQP.cpp:226-269): copies the scaled problem data the kernel holds

@@ -200,7 +200,9 @@ class BatchQP:
         _lib.check(_lib.lib().mpcqp_plan_info(self._h, a.ctypes.data))
         keys = ["n", "m", "batch", "npad", "mpad", "n_blocks", "L_blocks", "lds_bytes", "workspace_bytes_per_qp",
                 "ordering", "nnzP_triu", "nnzA", "T_blocks", "factor_ops", "ell_slots", "variant"]
-        return dict(zip(keys, a.tolist()))
+        d = dict(zip(keys, a.tolist()))
+        d["tiles"] = d["factor_ops"] if d["variant"] >= 200 else 0      # on-chip kernels report their dense tiles of A in that slot
+        return d
 
     def debug_scaling(self, b=0):
         D = np.empty(self.n); E = np.empty(self.m); c = np.empty(1)

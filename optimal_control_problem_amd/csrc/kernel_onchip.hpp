@@ -16,6 +16,18 @@
 // the next operand); the products of the factorisation (oc_ldl: 16x16 times 16x16, all sixteen columns in use) are four
 // v_mfma_f64_16x16x4_f64 each, with the operand layouts D(X) / A(X) described there.
 // =========================================================================================================
+// Dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan), device side
+struct DevTile {
+  int on, ntile;                  // tile ntile is the zero tile (no rows, all zeros): what a batch of four is padded with
+  int nAr, nAtr;                  // chunks of the two remainder layouts (= those of A and A')
+  const int *Ar_off, *Ar_idx, *Ar_src, *Atr_off, *Atr_idx, *Atr_src;
+  long Ar_entries, Atr_entries;
+  const int *tJ, *rowid, *tsrc;   // [ntile + 1], [(ntile + 1) * 16], [(ntile + 1) * 256] (set-up only)
+  const int *ta_info, *ta_cnt;    // [8 * chunks of A] {tile, column block, first row, rows} of the tiles with a row in the chunk (padded with the zero tile), [chunks] how many
+  const unsigned long long *ta_mask;   // [chunks of A] bit r: row 64 c + r gets a tile contribution
+  const int *tt_info;             // [4 * chunks of A'] {tile of column block J or the zero tile, first row, rows, 0}
+  long o_tile, o_ellAr, o_ellAtr; // slab offsets (doubles)
+};
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
@@ -23,6 +35,7 @@ struct DevOc {
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
   const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
+  DevTile tl;           // (last: the instances without tiles keep their argument layout)
 };
 
 // LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart, the four
@@ -89,6 +102,144 @@ __device__ __forceinline__ double oc_mv4x4(const d4 a, const d4 v, double acc) {
 }
 __device__ __forceinline__ double oc_ldE4(const double *vec, int p, const OcLane &ln) { return vec[BS * p + ln.o4]; }      // this lane's element of a vector block (the accumulator a product starts from)
 __device__ __forceinline__ int oc_tab(const int *tab, int k) { return __builtin_amdgcn_readfirstlane(tab[k]); }
+
+// ---- the two sweeps of the iteration on dense tiles (plan.hpp build_tile_plan): a tile is one 16 x 16 block of A's general rows, stored
+// once in the A-operand layout of the 4-block MFMA ([lane][K]: element (r, c) at lane r + 16 (c & 3), K = c >> 2).
+//   z~ = A x~ :  out = tile * x_J, the operand as it lies (one 32-byte load per lane), results (rows of A) in the lanes o4
+//   A' w      :  out = tile' * w_rows, the operand read transposed -- four 8-byte loads per lane, each instruction four whole 128-byte lines
+// Four tiles are in flight at a time (loads first, then sixteen interleaved MFMAs); a batch is padded with the zero tile.
+__device__ __forceinline__ int oc_tile_toff(const int lane) { return 4 * (lane >> 4) + 64 * (lane & 3) + ((lane >> 2) & 3); }     // doubles; + 16 K
+// Everything a chunk needs is requested at once -- the tile operands of its (up to four / eight) tiles and the first slots of its remainder
+// layout -- so that a chunk costs one round trip to memory, not one per step; the tables are per-chunk records of fixed size read with scalar
+// loads that depend on nothing but the chunk index (tile id, column block, first row, number of rows; the rows of a tile are consecutive).
+template <bool MAXABS, int UMAX>
+__device__ __forceinline__ double ell_chunk(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane);     // (kernel_resident.hpp)
+template <int U>
+struct EllPre { double v[U]; int ix[U]; };
+template <int U>
+__device__ __forceinline__ EllPre<U> ell_pre_load(const double *__restrict__ val, const int *__restrict__ idx, const int s0, const int s1, const int lane) {
+  EllPre<U> p;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    p.v[u] = 0.0; p.ix[u] = 0;
+    if (s0 + u < s1) { p.v[u] = val[(long)(s0 + u) * WAVE + lane]; p.ix[u] = idx[(long)(s0 + u) * WAVE + lane]; }
+  }
+  return p;
+}
+template <int U>
+__device__ __forceinline__ double ell_pre_sum(const EllPre<U> &p, const double *in) {
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; u++) acc += p.v[u] * in[p.ix[u]];
+  return acc;
+}
+// The per-chunk records ({tile, first row, rows} x 4 for a chunk of A' rows; {tile, column block, first row, rows} x 8, the tile count and
+// the 64-bit row mask for a chunk of A's rows) never change: each wave reads the records of ITS chunks once, before the ADMM loop, into the
+// lanes of a register per chunk (oc_tile_records), and the sweeps pick fields out with v_readlane -- no table access, scalar or vector, sits
+// in front of a chunk's loads any more (each was a full round trip to memory: the first tile version was twice as slow as the ELL sweeps).
+constexpr int OC_TILE_MAXA = 3, OC_TILE_MAXT = 2;      // chunks of A / A' rows per wave the tile instances keep records for (the host checks)
+struct OcTileRec { int a[OC_TILE_MAXA], t[OC_TILE_MAXT]; };
+template <int NW>
+__device__ __forceinline__ OcTileRec oc_tile_records(const DevTile &tl, const int nA, const int nAt, const int wid, const int lane) {
+  OcTileRec r;
+#pragma unroll
+  for (int k = 0; k < OC_TILE_MAXA; k++) {
+    const int c = wid + k * NW;
+    int v = (lane < 32 && (lane & 3) == 0) ? tl.ntile : 0;           // (no such chunk: eight zero tiles, no rows)
+    if (c < nA) {
+      if (lane < 32) v = tl.ta_info[32 * c + lane];
+      else if (lane == 32) v = tl.ta_cnt[c];
+      else if (lane == 33) v = (int)(tl.ta_mask[c] & 0xffffffffull);
+      else if (lane == 34) v = (int)(tl.ta_mask[c] >> 32);
+    }
+    r.a[k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < OC_TILE_MAXT; k++) {
+    const int c = wid + k * NW;
+    int v = (lane < 16 && (lane & 3) == 0) ? tl.ntile : 0;
+    if (c < nAt && lane < 16) v = tl.tt_info[16 * c + lane];
+    r.t[k] = v;
+  }
+  return r;
+}
+// the A' sweep of chunk c: R[t] = sigma x - q + sum over the chunk's four column blocks of tile' w_rows + remainder
+template <int U, class F>
+__device__ __forceinline__ void oc_tiles_at(const DevTile &tl, const int rec, const double *tiles, const double *valAtr, const int *coAtr, const double *W, double *R, const int c, const int nb,
+                                            const OcLane &ln, const int lane, F &&finish) {
+  const int toff = oc_tile_toff(lane);
+  int tid[4], first[4], rows[4]; d4 a[4], v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { tid[u] = __builtin_amdgcn_readlane(rec, 4 * u); first[u] = __builtin_amdgcn_readlane(rec, 4 * u + 1); rows[u] = __builtin_amdgcn_readlane(rec, 4 * u + 2); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const double *tp = tiles + (long)tid[u] * BLK + toff;
+    a[u] = d4{tp[0], tp[16], tp[32], tp[48]};
+  }
+  const int s0 = coAtr[c], s1 = coAtr[c + 1];
+  const EllPre<U> pre = ell_pre_load<U>(valAtr, tl.Atr_idx, s0, s1, lane);
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const double *wp = W + first[u] + ln.k4;
+    const int n = rows[u] - ln.k4;          // rows k4, k4 + 4, k4 + 8, k4 + 12 of the tile exist while below n
+    v[u] = d4{n > 0 ? wp[0] : 0.0, n > 4 ? wp[4] : 0.0, n > 8 ? wp[8] : 0.0, n > 12 ? wp[12] : 0.0};
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int K = 0; K < 4; K++)
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] = oc_mv4(a[u][K], v[u][K], acc[u]);
+#pragma unroll
+  for (int u = 0; u < 4; u++) if (4 * c + u < nb) R[BS * (4 * c + u) + ln.o4] = acc[u];
+  double e = ell_pre_sum<U>(pre, W);
+  if (s1 - s0 > U) e += ell_chunk<false, 8>(valAtr, tl.Atr_idx, W, s0 + U, s1, lane);
+  finish(c * WAVE + lane, e);
+}
+// the tile part of the A sweep of chunk c: W[row] = tile * x~_J for the rows of chunk c that lie in a tile (a tile whose rows straddle two
+// chunks is computed for both; each wave keeps its own rows); returns the remainder layout's row sums, *tiled = this lane's row has a tile part
+template <int U>
+__device__ __forceinline__ double oc_tiles_a(const DevTile &tl, const int rec, const double *tiles, const double *valAr, const int *coAr, const double *R, double *W, const int c,
+                                             const OcLane &ln, const int lane, bool *tiled) {
+  int tid[8], J[8], first[8], rows[8]; d4 a[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    tid[u] = __builtin_amdgcn_readlane(rec, 4 * u); J[u] = __builtin_amdgcn_readlane(rec, 4 * u + 1);
+    first[u] = __builtin_amdgcn_readlane(rec, 4 * u + 2); rows[u] = __builtin_amdgcn_readlane(rec, 4 * u + 3);
+  }
+  const int nt = __builtin_amdgcn_readlane(rec, 32);
+  const unsigned long long mask = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec, 34) << 32) | (unsigned)__builtin_amdgcn_readlane(rec, 33);
+  *tiled = (mask >> lane) & 1ull;
+  if (nt > 0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = reinterpret_cast<const d4 *>(tiles + (long)tid[u] * BLK)[lane];
+  }
+  if (nt > 4) {
+#pragma unroll
+    for (int u = 4; u < 8; u++) a[u] = reinterpret_cast<const d4 *>(tiles + (long)tid[u] * BLK)[lane];
+  }
+  const int s0 = coAr[c], s1 = coAr[c + 1];
+  const EllPre<U> pre = ell_pre_load<U>(valAr, tl.Ar_idx, s0, s1, lane);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (nt > 4 * h) {
+      d4 v[4]; double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = oc_ldB4(R, J[4 * h + u], ln);
+#pragma unroll
+      for (int K = 0; K < 4; K++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = oc_mv4(a[4 * h + u][K], v[u][K], acc[u]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rid = first[4 * h + u] + ln.o4;
+        if (ln.o4 < rows[4 * h + u] && (rid >> 6) == c) W[rid] = acc[u];
+      }
+    }
+  }
+  double e = ell_pre_sum<U>(pre, R);
+  if (s1 - s0 > U) e += ell_chunk<false, 8>(valAr, tl.Ar_idx, R, s0 + U, s1, lane);
+  return e;
+}
 
 // After a factorisation (or on a kept workspace): bring the factor from the slab on chip.  Off-diagonal blocks are stored
 // negated, so that every op of the sweeps is an accumulation  acc += block * v.
@@ -345,6 +496,18 @@ __device__ __forceinline__ void oc_touch(const void *base, const long bytes, con
     if (o + (long)lane * 128 < bytes) { int t; asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(p + o) : "memory"); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// The same with the loads' destination pinned: the compiler does not know that the asm statement above returns its result later -- it may hand
+// the destination register to something else (an address of the next trip) before the load has landed, and whether it does depends on the
+// register allocation of the instance: the round-2 instances happen not to (their ISA was checked: one register, only ever written by these
+// loads), an instance with tiles did, and faulted.  Here every load writes ONE register that stays an operand up to the final wait.
+__device__ __forceinline__ void oc_touch_pinned(const void *base, const long bytes, const int lane) {
+  const char *p = reinterpret_cast<const char *>(base) + (long)lane * 128;
+  int sink = 0;
+  for (long o = 0; o < bytes; o += 64 * 128) {
+    if (o + (long)lane * 128 < bytes) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p + o) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
 // Late rows of the right-hand side: the chains need the last vector blocks last, and waves 2, 3 are idle while they run.  So the sweep
 // over A' before the solve leaves out the chunk of the last chain positions (oc.at_poll) and the chunk of the hub's rows (oc.at_free, read

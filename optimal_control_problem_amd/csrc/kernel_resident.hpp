@@ -701,12 +701,14 @@ __device__ __forceinline__ int check_termination_res(RCtx &cx, Info &in, int app
 #define RZ_T0
 #define RZ_T(k)
 #endif
-template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false, int OCG = 0, int OCH = 0>
+// TL (on-chip instances): the two sweeps of the iteration run on dense tiles of A + the remainder ELL layouts (plan.hpp build_tile_plan)
+template <int NW, int MINW, bool GB, bool REUSE, bool ZYG = false, int OCG = 0, int OCH = 0, bool TL = false>
 __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
   constexpr bool OC = OCG > 0;
   static_assert(!OC || (GB && (NW == 4 || NW == 8)), "the on-chip solve is a mode of the 4- and 8-wave global-block kernels");
+  static_assert(!TL || OC, "tiles are a mode of the on-chip kernels");
   constexpr int OCU = NW == 4 ? 16 : 8;      // on-chip mode: ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
   constexpr int SPD = MINW == 3 ? 8 : 6;       // factor blocks in flight per wave in the global-block segment loops
   constexpr int EU = OC ? 8 : 16;   // ELL slots in flight per lane in the two sweeps of every iteration (8 for the 128-VGPR instances: 0.5 % slower; the on-chip mode needs the registers)
@@ -743,6 +745,9 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   int4 *segs = reinterpret_cast<int4 *>(cx.RED + 16 * NW);     // (block_combine needs 15 * NW) [2 * n_seg] schedule segments, then [NW + 1] list bounds
   int *lptr = reinterpret_cast<int *>(segs + 2 * rs.n_seg);
   volatile int *octicket = nullptr;                             // on-chip solve: wave 3's ticket for the late rows of the right-hand side
+  const int *coAr = nullptr, *coAtr = nullptr;                  // tiles: chunk offsets of the two remainder layouts (LDS)
+  double *tiles = nullptr, *valAr = nullptr, *valAtr = nullptr;
+  if constexpr (TL) { tiles = ws + oc.tl.o_tile; valAr = ws + oc.tl.o_ellAr; valAtr = ws + oc.tl.o_ellAtr; }
   int *octab = reinterpret_cast<int *>(cx.RED + 16 * NW) + 8;   // on-chip solve: its table (8-byte aligned pairs) instead of schedule segments
   double *ocBL = lds;                                           // ... and the LDS block slots (the temp tiles of the factorisation alias them)
   d4 ocG[OC ? OCG : 1], ocHF[OCH > 0 ? OCH : 1], ocHT[OCH > 0 ? OCH : 1];
@@ -768,6 +773,12 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
     cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
     octicket = co + pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3;
     if (tid == 0) *octicket = 0;
+    if constexpr (TL) {      // ... and of the two remainder layouts, behind the ticket
+      int *cr = co + pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 4;
+      for (int k = tid; k <= oc.tl.nAr; k += NT) cr[k] = oc.tl.Ar_off[k];
+      for (int k = tid; k <= oc.tl.nAtr; k += NT) cr[oc.tl.nAr + 1 + k] = oc.tl.Atr_off[k];
+      coAr = cr; coAtr = cr + oc.tl.nAr + 1;
+    }
     ocl = oc_lane(lane);
   } else {
     for (int k = tid; k < 2 * rs.n_seg; k += NT) segs[k] = reinterpret_cast<const int4 *>(rs.g_seg)[k];
@@ -872,6 +883,29 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       ell_map_chunk<GB>(sAt, pl.At.src, inA, pl.At.idx, valAt, cx.coAt[ch], cx.coAt[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
       ell_map_chunk<false>(sP, pl.P.idx, nullptr, pl.P.idx, valP, cx.coP[ch], cx.coP[ch + 1], lane, [&](double v, int k) { return v * (c * dj * cx.R[k]); });
     }
+    if constexpr (TL) {
+      // the same scaled numbers once more in the layouts of the iteration's sweeps: dense tiles ([lane][K] order; element (r, c) of tile t is
+      // row rowid[16 t + r], position 16 tJ[t] + c) and the two remainder layouts, gathered from the caller's array
+      const DevTile &tl = oc.tl;
+      for (long e = tid; e < (long)tl.ntile * BLK; e += NT) {
+        const int sidx = tl.tsrc[e];
+        double v = 0.0;
+        if (sidx >= 0) {
+          const int t = (int)(e >> 8), lt = (int)(e >> 2) & 63, K = (int)e & 3;
+          const int i = tl.rowid[t * BS + (lt & 15)], j = BS * tl.tJ[t] + (lt >> 4) + 4 * K;
+          v = inA[sidx] * (cx.W[i] * cx.R[j]);
+        }
+        tiles[e] = v;
+      }
+      for (int ch = wid; ch < tl.nAr; ch += NW) {
+        const int i = ch * WAVE + lane; const double ei = i < mpad ? cx.W[i] : 0.0;
+        ell_map_chunk<true>(valAr, tl.Ar_src, inA, tl.Ar_idx, valAr, coAr[ch], coAr[ch + 1], lane, [&](double v, int j) { return v * (ei * cx.R[j]); });
+      }
+      for (int ch = wid; ch < tl.nAtr; ch += NW) {
+        const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+        ell_map_chunk<true>(valAtr, tl.Atr_src, inA, tl.Atr_idx, valAtr, coAtr[ch], coAtr[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
+      }
+    }
     bsync<NW>();
     for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
     for (int i = tid; i < mpad; i += NT) {
@@ -931,12 +965,32 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
   // the start of the next iteration -- into L2 (every iteration re-reads them, and 512 resident QPs x 90 KB do not stay in L2 by themselves)
   auto idle_touch = [&](const int w) {
     if (io.no_touch) return;
+    if constexpr (TL) {
+      if (w == 2) oc_touch_pinned(tiles, (long)oc.tl.ntile * BLK * 8, lane);
+      else if (NW == 4 || w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAr, oc.tl.Ar_entries * 8, lane); oc_touch_pinned(valAtr, oc.tl.Atr_entries * 8, lane); }
+      return;
+    }
+    if constexpr (NW == 8) {      // (the eight-wave instances are new in round 3: pinned form; off unless MPCQP_TOUCH8)
+      if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
+      else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
+      return;
+    }
     if (w == 2) oc_touch(valA, pl.A.entries * 8, lane);
     else if (NW == 4 || w == 3) { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
   };
+  OcTileRec trec;
+  if constexpr (TL) trec = oc_tile_records<NW>(oc.tl, pl.A.nchunks, pl.At.nchunks, wid, lane);      // this wave's chunk records, for the whole solve
   if (ok) {
     int iter;
     for (iter = 1; iter <= st.max_iter; iter++) {
+      if constexpr (TL) {     // tiles: per chunk the four column blocks' tile products into R, then the remainder layout on top
+#pragma unroll
+        for (int k = 0; k < OC_TILE_MAXT; k++) {
+          const int c = wid + k * NW;
+          if (c < pl.At.nchunks)
+            oc_tiles_at<4>(oc.tl, trec.t[k], tiles, valAtr, coAtr, cx.W, cx.R, c, pl.nb, ocl, lane, [&](const int t, const double v) { if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + (v + cx.R[t]); });
+        }
+      } else
       if constexpr (OC) {     // (the chunks named in oc.at_poll / oc.at_free are computed during the chain phase of the solve: oc_solve)
         for (int c = wid; c < pl.At.nchunks; c += NW) if (c != oc.at_poll && c != oc.at_free) {
           const int t = c * WAVE + lane;
@@ -950,10 +1004,10 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        if constexpr (NW == 4) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        if constexpr (NW == 4 && !TL) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
         else oc_solve_long<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);
 #else
-        if constexpr (NW == 4) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
+        if constexpr (NW == 4 && !TL) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
         else oc_solve_long<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);
 #endif
       } else {
@@ -987,6 +1041,20 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
             if (save) dyg[i] = dy;
           }
         };
+        if constexpr (TL) {     // tiles: the rows of a chunk that lie in a tile get that part through w (dead until row_update rewrites it)
+#pragma unroll
+          for (int k = 0; k < OC_TILE_MAXA; k++) {
+            const int c = wid + k * NW;
+            if (c < pl.A.nchunks) {
+              const int i = c * WAVE + lane;
+              const double lo = lb[i], up = ub[i];
+              const double zo = (ZYG && i < mpad) ? cx.Z[i] : 0.0, yp = (ZYG && i < mpad) ? cx.Y[i] : 0.0;
+              bool tiled;
+              const double ze = oc_tiles_a<2>(oc.tl, trec.a[k], tiles, valAr, coAr, cx.R, cx.W, c, ocl, lane, &tiled);
+              row_update(i, lo, up, zo, yp, tiled ? ze + cx.W[i] : ze);
+            }
+          }
+        } else
         for (int c = wid; c < pl.A.nchunks; c += NW) {
           const int i = c * WAVE + lane;
           const double lo = lb[i], up = ub[i];

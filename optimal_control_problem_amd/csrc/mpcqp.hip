@@ -85,6 +85,7 @@ struct mpcqp_handle {
   bool oc = false;              // on-chip mode of the global-block kernel (kernel_onchip.hpp): two workgroups per CU, factor in LDS + registers
   int oc8 = 0;                  // ... its eight-wave instances for long chains (one workgroup per CU): 1 = <NG 4, NH 4>, 2 = <NG 7, NH 5, z / y in the slab>
   OcPlan ocplan; DevOc doc;
+  TilePlan tplan; bool tiles = false;   // on-chip kernels: dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
@@ -150,6 +151,9 @@ constexpr int OC8_MAX_CHAIN = 64;           // (oc_ldl keeps the chain's block i
 // full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
 template <bool REUSE>
 static const void *res_kernel_pick(const mpcqp_handle *h) {
+  if (h->oc && h->tiles && h->oc8 == 1) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[0].zyg, OC8_INST[0].ng, OC8_INST[0].nh, true>;
+  if (h->oc && h->tiles && h->oc8 == 2) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh, true>;
+  if (h->oc && h->tiles) return (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH, true>;
   if (h->oc && h->oc8 == 1) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[0].zyg, OC8_INST[0].ng, OC8_INST[0].nh>;
   if (h->oc && h->oc8 == 2) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh>;
   if (h->oc) return h->ocplan.has_hub ? (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, 0>;
@@ -331,7 +335,17 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     if (want > 0) { h->plan = want >= 2 ? p4 : p1; h->wl = ws_layout(h->plan); }
     if (want > 0) {
       h->rplan = build_res_plan(pl, want, h->gblocks && !h->oc);
-      long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      if (h->oc && h->ocplan.has_hub && getenv("MPCQP_TILES") && getenv("MPCQP_TILES")[0] == '1') {
+        // EXPERIMENTAL, opt-in (MPCQP_TILES=1): dense tiles for the two sweeps of the iteration where the pattern has them (dense Jacobian
+        // blocks: the quadrotor's 12 x 16 per stage) and the LDS still fits.  Parity-green, but measured SLOWER than the ELL sweeps in these
+        // register-bound instances (quadrotor N = 20 x 8192: 12.0 - 13.7 ms against 8.68), so the default stays ELL.
+        h->tplan = build_tile_plan(pl, n, m, Ap, Ai, 2);
+        h->tiles = h->tplan.on && h->tplan.max_per_block <= 1 && h->tplan.max_per_chunk <= 8 && h->tplan.rows_consecutive &&
+                   pl.A.nchunks <= 3 * want && pl.At.nchunks <= 2 * want &&      // (kernel_onchip.hpp OC_TILE_MAXA / OC_TILE_MAXT chunk records per wave)
+                   lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg, &h->tplan) <= (h->oc8 ? OC8_LDS_MAX : OC_LDS_MAX);
+        if (h->tiles) h->wl = ws_layout(pl, &h->tplan);
+      }
+      long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg, h->tiles ? &h->tplan : nullptr) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
       if (h->gblocks && !h->oc && want == 4 && !getenv("MPCQP_NO_ZYG")) {     // (the two-wave global-block kernel has no such instance: forced on a long horizon it took this layout and returned garbage)
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
         const long alt = lds_bytes_res_gb(pl, h->rplan, true);
@@ -385,11 +399,43 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
-      if (getenv("MPCQP_LATE")) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
+      if (getenv("MPCQP_LATE") && !h->tiles) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));
       UP(upload(h, oc_asm_records(pl), &d.asm_rec));
+      if (h->tiles) {
+        const TilePlan &tp = h->tplan; DevTile &t = d.tl;
+        t.on = 1; t.ntile = tp.ntile; t.nAr = tp.Ar.nchunks; t.nAtr = tp.Atr.nchunks; t.Ar_entries = tp.Ar.entries(); t.Atr_entries = tp.Atr.entries();
+        UP(upload(h, tp.Ar.chunk_off, &t.Ar_off)); UP(upload(h, tp.Ar.idx, &t.Ar_idx)); UP(upload(h, tp.Ar.src, &t.Ar_src));
+        UP(upload(h, tp.Atr.chunk_off, &t.Atr_off)); UP(upload(h, tp.Atr.idx, &t.Atr_idx)); UP(upload(h, tp.Atr.src, &t.Atr_src));
+        UP(upload(h, tp.tJ, &t.tJ)); UP(upload(h, tp.rowid, &t.rowid)); UP(upload(h, tp.tsrc, &t.tsrc));
+        {   // per-chunk records of fixed size (kernel_onchip.hpp oc_tiles_a / oc_tiles_at): {tile, column block, first row, rows}, padded with the zero tile
+          auto first = [&](int tt) { for (int r = 0; r < BS; r++) if (tp.rowid[(size_t)tt * BS + r] >= 0) return tp.rowid[(size_t)tt * BS + r]; return 0; };
+          auto rows = [&](int tt) { int k = 0; for (int r = 0; r < BS; r++) k += tp.rowid[(size_t)tt * BS + r] >= 0; return k; };
+          std::vector<int> ai(32 * (size_t)pl.A.nchunks, 0), ac(pl.A.nchunks, 0);
+          for (int c = 0; c < pl.A.nchunks; c++) {
+            ac[c] = tp.ta_ptr[c + 1] - tp.ta_ptr[c];
+            for (int u = 0; u < 8; u++) {
+              const int tt = u < ac[c] ? tp.ta_tid[tp.ta_ptr[c] + u] : tp.ntile;
+              int rec[4] = {tt, tp.tJ[tt], first(tt), rows(tt)};
+              std::copy(rec, rec + 4, ai.begin() + 32 * (size_t)c + 4 * u);
+            }
+          }
+          UP(upload(h, ai, &t.ta_info)); UP(upload(h, ac, &t.ta_cnt));
+          std::vector<int> ti(16 * (size_t)pl.At.nchunks, 0);
+          for (int J = 0; J < 4 * pl.At.nchunks; J++) {
+            const int tt = (J < pl.nb && tp.tt_ptr[J + 1] > tp.tt_ptr[J]) ? tp.tt_tid[tp.tt_ptr[J]] : tp.ntile;
+            int rec[4] = {tt, first(tt), rows(tt), 0};
+            std::copy(rec, rec + 4, ti.begin() + 4 * (size_t)J);
+          }
+          UP(upload(h, ti, &t.tt_info));
+        }
+        std::vector<unsigned long long> mask(pl.A.nchunks, 0ull);
+        for (size_t k = 0; k < (size_t)tp.ntile * BS; k++) if (tp.rowid[k] >= 0) mask[tp.rowid[k] / WAVE] |= 1ull << (tp.rowid[k] % WAVE);
+        UP(upload(h, mask, &t.ta_mask));
+        t.o_tile = h->wl.tile; t.o_ellAr = h->wl.ellAr; t.o_ellAtr = h->wl.ellAtr;
+      }
     }
   }
   const WsLayout &w = h->wl;
@@ -863,7 +909,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   if (h->inner) return mpcqp_plan_info(h->inner, o);        // the plan that runs: the reduced pattern's
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
-  o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = (long)pl.fac.size();
+  o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = h->oc ? (h->tiles ? h->tplan.ntile : 0) : (long)pl.fac.size();
   o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->oc ? 200 + h->variant : h->gblocks ? 100 + h->variant : h->variant;
   return MPCQP_OK;
 }

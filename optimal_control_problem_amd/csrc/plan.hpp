@@ -393,11 +393,111 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
   return pl;
 }
 
+// ---- dense tiles of A for the two sweeps of the ADMM iteration (on-chip kernels)
+// The dynamics rows of a stage OCP carry a dense Jacobian block per stage (12 x 16 on the 12-state quadrotor): in the ELL layouts those rows
+// are 17 slots wide, A and A' are two copies of the same numbers (77 KB per QP and iteration), and a sweep is a chain of dependent load
+// batches.  Here general rows are grouped by the 16-column block that holds most of their entries; a group of up to 16 rows whose entries in
+// that block are dense enough becomes a 16 x 16 tile, stored once, in the operand layout of the 4-block MFMA -- element (r, c) at
+// [lane = r + 16 (c & 3)][K = c >> 2] -- which serves A x as it is (one 32-byte load per lane) and A' w through four 8-byte loads per lane
+// (each instruction four whole 128-byte lines).  What is left of A (singleton rows, the entries outside the tiles) stays in ELL form
+// (Ar by row, Atr by variable, same row / lane mapping as A / A').  Values are the same numbers as in the ELL arrays (same scaling
+// expression); only the order of summation inside a row differs.
+struct TilePlan {
+  bool on = false;
+  int ntile = 0;
+  std::vector<int> tJ;            // [ntile + 1] column block; the last entry is the zero tile (never written, all rows padding)
+  std::vector<int> rowid;         // [(ntile + 1) * 16] row of A behind row r of the tile, -1 = padding
+  std::vector<int> tsrc;          // [(ntile + 1) * 256] index into the caller's A values, storage order [lane][K], -1 = structural zero
+  Ell Ar, Atr;                    // A and A' without the tile entries
+  std::vector<int> ta_ptr, ta_tid;   // tiles with a row in chunk c of A's rows: ta_tid[ta_ptr[c] .. ta_ptr[c + 1])
+  std::vector<int> tt_ptr, tt_tid;   // tiles of column block J: tt_tid[tt_ptr[J] .. tt_ptr[J + 1])
+  int max_per_chunk = 0, max_per_block = 0;
+  bool rows_consecutive = true;   // the rows of every tile are consecutive rows of A (what the kernels' per-tile {first row, rows} records assume)
+  long entries_in_tiles = 0;
+};
+constexpr int TILE_MIN_PER_ROW = 6;       // a group becomes a tile when its rows have on average this many entries in its block ...
+constexpr int TILE_MIN_ENTRIES = 72;      // ... and at least this many together
+
+inline TilePlan build_tile_plan(const Plan &pl, int n, int m, const int *Ap, const int *Ai, int pad) {
+  TilePlan tp;
+  struct RE { int col, src; };
+  std::vector<std::vector<RE>> arow(m);
+  for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) arow[Ai[k]].push_back({j, k});
+  // dominant block of every general row
+  std::vector<int> dom(m, -1), cnt(m, 0);
+  for (int i = 0; i < m; i++) if (!pl.singleton[i]) {
+    std::map<int, int> c;
+    for (auto &e : arow[i]) c[pl.pos[e.col] / BS]++;
+    for (auto &kv : c) if (kv.second > cnt[i]) { cnt[i] = kv.second; dom[i] = kv.first; }
+  }
+  std::vector<char> in_tile(pl.nnzA_in, 0);
+  std::vector<int> group;
+  auto flush = [&]() {
+    if (group.empty()) return;
+    long tot = 0; for (int i : group) tot += cnt[i];
+    if (tot >= TILE_MIN_ENTRIES && tot >= (long)TILE_MIN_PER_ROW * (long)group.size()) {
+      const int J = dom[group[0]], t = tp.ntile++;
+      tp.tJ.push_back(J);
+      tp.rowid.resize((size_t)(t + 1) * BS, -1); tp.tsrc.resize((size_t)(t + 1) * BLK, -1);
+      for (size_t r = 0; r < group.size(); r++) {
+        const int i = group[r];
+        tp.rowid[(size_t)t * BS + r] = i;
+        for (auto &e : arow[i]) if (pl.pos[e.col] / BS == J) {
+          const int c = pl.pos[e.col] % BS;
+          tp.tsrc[(size_t)t * BLK + ((int)r + BS * (c & 3)) * 4 + (c >> 2)] = e.src;
+          in_tile[e.src] = 1; tp.entries_in_tiles++;
+        }
+      }
+    }
+    group.clear();
+  };
+  for (int i = 0; i < m; i++) {
+    if (pl.singleton[i] || dom[i] < 0) { flush(); continue; }
+    if (!group.empty() && (dom[group[0]] != dom[i] || (int)group.size() == BS)) flush();
+    group.push_back(i);
+  }
+  flush();
+  if (tp.ntile == 0) return tp;
+  tp.on = true;
+  // the zero tile: block 0, no rows, no entries
+  tp.tJ.push_back(0); tp.rowid.resize((size_t)(tp.ntile + 1) * BS, -1); tp.tsrc.resize((size_t)(tp.ntile + 1) * BLK, -1);
+  // remainder ELL layouts (same row -> lane and variable -> lane mapping as A and A')
+  {
+    std::vector<std::vector<EllEntry>> rows(m);
+    for (int i = 0; i < m; i++) for (auto &a : arow[i]) if (!in_tile[a.src]) rows[i].push_back({pl.pos[a.col], a.src, 0});
+    tp.Ar = build_ell(rows, pad);
+  }
+  {
+    std::vector<std::vector<EllEntry>> rows(pl.npad);
+    for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) if (!in_tile[k]) rows[pl.pos[j]].push_back({Ai[k], k, pl.singleton[Ai[k]]});
+    tp.Atr = build_ell(rows, pad);
+  }
+  // which tiles a chunk of A's rows needs (a tile whose rows straddle two chunks is listed in both), which tiles a column block has
+  const int nA = pl.A.nchunks;
+  std::vector<std::vector<int>> per_chunk(nA), per_block(pl.nb);
+  for (int t = 0; t < tp.ntile; t++) {
+    std::set<int> cs;
+    for (int r = 0; r < BS; r++) if (tp.rowid[(size_t)t * BS + r] >= 0) cs.insert(tp.rowid[(size_t)t * BS + r] / WAVE);
+    for (int c : cs) per_chunk[c].push_back(t);
+    per_block[tp.tJ[t]].push_back(t);
+  }
+  for (int t = 0; t < tp.ntile; t++) for (int r = 1; r < BS; r++) {
+    const int a = tp.rowid[(size_t)t * BS + r - 1], b = tp.rowid[(size_t)t * BS + r];
+    if (b >= 0 && b != a + 1) tp.rows_consecutive = false;
+  }
+  tp.ta_ptr.push_back(0);
+  for (int c = 0; c < nA; c++) { for (int t : per_chunk[c]) tp.ta_tid.push_back(t); tp.ta_ptr.push_back((int)tp.ta_tid.size()); tp.max_per_chunk = std::max(tp.max_per_chunk, (int)per_chunk[c].size()); }
+  tp.tt_ptr.push_back(0);
+  for (int J = 0; J < pl.nb; J++) { for (int t : per_block[J]) tp.tt_tid.push_back(t); tp.tt_ptr.push_back((int)tp.tt_tid.size()); tp.max_per_block = std::max(tp.max_per_block, (int)per_block[J].size()); }
+  return tp;
+}
+
 // workspace layout per QP, in doubles; every section starts on a 16-double (128 B) boundary
 struct WsLayout {
   long ellA = 0, ellAt = 0, ellP = 0, Lf = 0, Lb = 0, T = 0, l = 0, u = 0, D = 0, E = 0, dx = 0, dy = 0, Zg = 0, Yg = 0, stride = 0;
+  long tile = 0, ellAr = 0, ellAtr = 0;      // dense tiles of A + the remainder ELL values (on-chip kernels with a TilePlan), behind everything else
 };
-inline WsLayout ws_layout(const Plan &pl) {
+inline WsLayout ws_layout(const Plan &pl, const TilePlan *tp = nullptr) {
   WsLayout w; long o = 0;
   auto take = [&](long cnt) { long r = o; o += (cnt + 15) / 16 * 16; return r; };
   w.ellA = take(pl.A.entries()); w.ellAt = take(pl.At.entries()); w.ellP = take(pl.P.entries());
@@ -406,6 +506,7 @@ inline WsLayout ws_layout(const Plan &pl) {
   w.l = take(pl.mpad); w.u = take(pl.mpad); w.D = take(pl.npad); w.E = take(pl.mpad);
   w.dx = take(pl.npad); w.dy = take(pl.mpad);
   w.Zg = take(pl.mpad); w.Yg = take(pl.mpad);   // z, y of the kernels that keep them out of LDS (row-indexed only, like l and u)
+  if (tp && tp->on) { w.tile = take(((long)tp->ntile + 1) * BLK); w.ellAr = take(tp->Ar.entries()); w.ellAtr = take(tp->Atr.entries()); }
   w.stride = o;
   return w;
 }
@@ -814,9 +915,10 @@ inline long oc_stage_doubles(const OcPlan &oc, const ResPlan &rp, const Plan &pl
   // block slots / temp tiles, or the factorisation's scratch: 8 hand-over blocks + the assembly records (4 doubles per block)
   return std::max((long)std::max(oc.nlds, rp.ntemp) * BLK, 8L * BLK + ((4L * pl.nblk + 15) / 16) * 16);   // (8: kernel_onchip.hpp OC_LDL_SCR)
 }
-inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc, bool zy_global = false) {
+inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc, bool zy_global = false, const TilePlan *tp = nullptr) {
   // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
-  const long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1 + 1) / 2;     // (+ the ticket of the late right-hand side rows)
+  long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1 + 1) / 2;     // (+ the ticket of the late right-hand side rows)
+  if (tp && tp->on) tab_words += ((long)tp->Ar.nchunks + tp->Atr.nchunks + 2 + 1) / 2;      // chunk offsets of the two remainder layouts
   return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + oc_rext(rp.nw) + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 

@@ -697,6 +697,71 @@ extern "C" int plan_execute_oc(int n, int m, const int *Pp, const int *Pi, const
   return plan_execute_oc_nw(n, m, Pp, Pi, Ap, Ai, 4, NG, NH, ldl, 0, Pval, Aval, rho, sigma, rhs, sol, info);
 }
 
+// Dense tiles of A for the iteration's two sweeps (plan.hpp build_tile_plan): A x and A' w from the tiles -- through the 4-block MFMA in the
+// lane layouts the kernel uses (tile storage [lane][K] read as it is for A x, as its transpose for A' w; results in the lanes o4) -- plus the
+// remainder ELL layouts, against the plain CSC products.  ordering / pad as the on-chip plans (2: four-wave, 3: eight-wave).
+// returns 0 ok, 1 plan error, 4 no tiles found, 6 table inconsistency, 7 products differ; out = [ntile, entries in tiles, Ar slots, Atr slots, A slots, At slots, max tiles per chunk, max per block]
+extern "C" int plan_tile_check(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int ordering, const double *Aval, const double *x, const double *w,
+                               double *err, long *out) {
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, ordering, 2);
+  if (!pl.error.empty()) return 1;
+  TilePlan tp = build_tile_plan(pl, n, m, Ap, Ai, 2);
+  if (out) { out[0] = tp.ntile; out[1] = tp.entries_in_tiles; out[2] = tp.on ? tp.Ar.slots() : 0; out[3] = tp.on ? tp.Atr.slots() : 0; out[4] = pl.A.slots(); out[5] = pl.At.slots();
+             out[6] = tp.max_per_chunk; out[7] = tp.max_per_block; }
+  if (!tp.on) return 4;
+  // every entry of A exactly once: in a tile or in each remainder layout
+  std::vector<int> seenA(pl.nnzA_in, 0), seenT(pl.nnzA_in, 0);
+  for (size_t e = 0; e < tp.tsrc.size(); e++) if (tp.tsrc[e] >= 0) { seenA[tp.tsrc[e]]++; seenT[tp.tsrc[e]]++; }
+  for (size_t e = 0; e < tp.Ar.src.size(); e++) if (tp.Ar.src[e] >= 0) seenA[tp.Ar.src[e]]++;
+  for (size_t e = 0; e < tp.Atr.src.size(); e++) if (tp.Atr.src[e] >= 0) seenT[tp.Atr.src[e]]++;
+  for (int k = 0; k < pl.nnzA_in; k++) if (seenA[k] != 1 || seenT[k] != 1) return 6;
+  for (int t = 0; t < tp.ntile; t++) for (int r = 0; r < BS; r++) {
+    const int i = tp.rowid[(size_t)t * BS + r];
+    if (i >= m) return 6;
+    if (i >= 0) { bool listed = false; for (int q = tp.ta_ptr[i / WAVE]; q < tp.ta_ptr[i / WAVE + 1]; q++) listed |= tp.ta_tid[q] == t; if (!listed) return 6; }
+  }
+  std::vector<double> xp(pl.npad, 0.0), ax(m, 0.0), atw(pl.npad, 0.0);
+  for (int j = 0; j < n; j++) xp[pl.pos[j]] = x[j];
+  auto tval = [&](int t, int e) { const int sidx = tp.tsrc[(size_t)t * BLK + e]; return sidx >= 0 ? Aval[sidx] : 0.0; };
+  // A x
+  for (int t = 0; t < tp.ntile; t++) {
+    Wave a, v = ldB4(xp.data(), tp.tJ[t]);
+    for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) a.v[l][K] = tval(t, l * 4 + K);
+    Wave1 acc = zero1(); mv4(a, v, acc);
+    for (int l = 0; l < 64; l++) if ((l & 3) == 0) { const int r = 4 * ((l >> 2) & 3) + (l >> 4), i = tp.rowid[(size_t)t * BS + r]; if (i >= 0) ax[i] += acc.v[l]; }
+  }
+  for (int c = 0; c < tp.Ar.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    const int i = c * WAVE + lane; if (i >= m) continue;
+    for (int sl = tp.Ar.chunk_off[c]; sl < tp.Ar.chunk_off[c + 1]; sl++) { const long e = (long)sl * WAVE + lane; if (tp.Ar.src[e] >= 0) ax[i] += Aval[tp.Ar.src[e]] * xp[tp.Ar.idx[e]]; }
+  }
+  // A' w
+  for (int J = 0; J < pl.nb; J++) for (int q = tp.tt_ptr[J]; q < tp.tt_ptr[J + 1]; q++) {
+    const int t = tp.tt_tid[q];
+    if (tp.tJ[t] != J) return 6;
+    Wave a, v;
+    for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) {
+      const int r = (l >> 4) + 4 * K, c = l & 15;
+      a.v[l][K] = tval(t, (r + BS * (c & 3)) * 4 + (c >> 2));
+      const int i = tp.rowid[(size_t)t * BS + r];
+      v.v[l][K] = i >= 0 ? w[i] : 0.0;
+    }
+    Wave1 acc = zero1(); mv4(a, v, acc);
+    for (int l = 0; l < 64; l++) if ((l & 3) == 0) atw[BS * J + 4 * ((l >> 2) & 3) + (l >> 4)] += acc.v[l];
+  }
+  for (int c = 0; c < tp.Atr.nchunks; c++) for (int lane = 0; lane < WAVE; lane++) {
+    const int t = c * WAVE + lane; if (t >= pl.npad) continue;
+    for (int sl = tp.Atr.chunk_off[c]; sl < tp.Atr.chunk_off[c + 1]; sl++) { const long e = (long)sl * WAVE + lane; if (tp.Atr.src[e] >= 0) atw[t] += Aval[tp.Atr.src[e]] * w[tp.Atr.idx[e]]; }
+  }
+  // reference products
+  double worst = 0.0, scale = 1.0;
+  std::vector<double> rax(m, 0.0), ratw(pl.npad, 0.0);
+  for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) { rax[Ai[k]] += Aval[k] * x[j]; ratw[pl.pos[j]] += Aval[k] * w[Ai[k]]; }
+  for (int i = 0; i < m; i++) { worst = std::max(worst, std::fabs(ax[i] - rax[i])); scale = std::max(scale, std::fabs(rax[i])); }
+  for (int t = 0; t < pl.npad; t++) { worst = std::max(worst, std::fabs(atw[t] - ratw[t])); scale = std::max(scale, std::fabs(ratw[t])); }
+  if (err) *err = worst / scale;
+  return worst <= 1e-12 * scale ? 0 : 7;
+}
+
 // chunk widths of the three ELL structures (diagnostic): out = [nA, widths..., nAt, widths..., nP, widths...]
 extern "C" int plan_ell_widths(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int pad4, int *out, int cap) {
   Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, 2, pad4 != 0);

@@ -956,3 +956,23 @@ def test_two_wave_global_block_kernel_on_a_long_horizon(built, monkeypatch):
     assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
     for k in ("x", "y", "z"):
         _close(got, ref, k)
+
+
+@pytest.mark.parametrize("name,B,N", [("quadrotor", 12, 20), ("quadrotor", 6, 50), ("quadrotor", 5, 30)])
+def test_experimental_tile_sweeps_vs_oracle(built, monkeypatch, name, B, N):
+    """MPCQP_TILES=1 (opt-in, experimental): the iteration's two sweeps on dense 16 x 16 tiles of A through the 4-block MFMA + remainder ELL
+    layouts (plan.hpp build_tile_plan) -- same numbers as the ELL arrays, another summation order: same bar as every family"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_TILES", "1")
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info()
+    assert info["variant"] in (204, 208) and info["tiles"] == N - 1          # one tile per dynamics stage
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+    monkeypatch.delenv("MPCQP_TILES")
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
+    assert info["tiles"] == 0                                                # default: ELL sweeps

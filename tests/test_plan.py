@@ -226,6 +226,25 @@ def test_onchip_long_chain_plan_emulated(built, name, N, inst, expect, ldl):
         assert _run_oc(ls)[0] == 5                         # ... and the four-wave plan does not take it
 
 
+@pytest.mark.parametrize("name,N,order,ntile", [("quadrotor", 20, 2, 19), ("quadrotor", 50, 3, 49), ("quadrotor", 10, 2, 9), ("cartpole", 100, 3, 0), ("double_integrator", 20, 2, 0)])
+def test_tile_plan_products(built, name, N, order, ntile):
+    """dense tiles of A for the iteration's sweeps (plan.hpp build_tile_plan; opt-in MPCQP_TILES=1): every entry of A exactly once in a tile or
+    in each remainder layout; A x and A' w from the tiles -- through the emulated 4-block MFMA in the kernel's lane layouts -- plus the
+    remainders equal the CSC products; patterns without dense blocks get no tiles"""
+    L = C.CDLL(SO)
+    L.plan_tile_check.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    rng = np.random.default_rng(0)
+    Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[1]); x = rng.normal(size=ls.n); w = rng.normal(size=ls.m)
+    err = C.c_double(0); out = np.zeros(8, np.int64)
+    rc = L.plan_tile_check(ls.n, ls.m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), order, _p(Av), _p(x), _p(w), C.byref(err), _p(out))
+    if ntile == 0:
+        assert rc == 4 and out[0] == 0
+        return
+    assert rc == 0 and out[0] == ntile and err.value < 1e-13
+    assert out[2] < out[4] / 4 and out[3] < out[5] / 4 and out[7] == 1          # the remainders are a fraction of the ELL layouts; one tile per column block
+
+
 def test_onchip_long_chain_plan_limits(built):
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=57)          # 57 chain blocks: more than seven positions per wave
     assert _run_oc8(ls, 7, 5, 1)[0] == 5
