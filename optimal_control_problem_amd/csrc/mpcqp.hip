@@ -102,7 +102,7 @@ struct mpcqp_handle {
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
   hipStream_t last_stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev0r = nullptr;   // (ev0r: reduced handles, ordering of the presolve behind a solve on another stream)
   // reduced form (mpcqp_create_reduced): this handle keeps the caller's dimensions, `inner` solves the QP without the eliminated variables
   mpcqp_handle *inner = nullptr; RedMaps red; DevRed dred; double *rx0 = nullptr, *ry0 = nullptr;
 };
@@ -594,10 +594,12 @@ int mpcqp_create_reduced(int n, int m, int batch, const int *Pp, const int *Pi, 
   UP(dalloc(h, &d.Pr, B * std::max(d.nnzPr, 1))); UP(dalloc(h, &d.qr, B * rm.nr)); UP(dalloc(h, &d.Ar, B * std::max(d.nnzAr, 1)));
   UP(dalloc(h, &d.lr, B * std::max(rm.mr, 1))); UP(dalloc(h, &d.ur, B * std::max(rm.mr, 1))); UP(dalloc(h, &d.xfix, B * std::max(rm.nfix, 1)));
   UP(dalloc(h, &d.bad, B));
+  if (h->st.warm_start) { UP(dalloc(h, &h->rx0, B * rm.nr)); UP(dalloc(h, &h->ry0, B * std::max(rm.mr, 1))); }     // (nothing is allocated inside a solve: it stays graph-capturable)
   UP(dalloc(h, &h->ox, B * n)); UP(dalloc(h, &h->oy, B * m)); UP(dalloc(h, &h->oz, B * m));
   UP(dalloc(h, &h->oinfo, B * 4)); UP(dalloc(h, &h->ostatus, B)); UP(dalloc(h, &h->oiters, B));
 #undef UP
   memset(&h->io, 0, sizeof(h->io));
+  if (hipEventCreateWithFlags(&h->ev0r, hipEventDisableTiming) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   *out = h;
   return MPCQP_OK;
 }
@@ -606,6 +608,8 @@ int mpcqp_create_reduced(int n, int m, int batch, const int *Pp, const int *Pi, 
 static int solve_reduced(mpcqp_handle *h, hipStream_t s) {
   mpcqp_handle *in = h->inner; const DevRed &d = h->dred;
   const bool vectors = h->reuse_next;
+  // the presolve overwrites the reduced arrays the previous solve of this handle read: if that one ran on another stream, wait for it
+  if (h->solved && h->last_stream != s) { HIPCHK(hipEventRecord(h->ev0r, h->last_stream)); HIPCHK(hipStreamWaitEvent(s, h->ev0r, 0)); }
   hipLaunchKernelGGL(mpcqp_presolve_kernel, dim3(h->batch), dim3(256), 0, s, d, h->io, vectors ? 1 : 0);
   HIPCHK(hipGetLastError());
   int rc;
@@ -613,7 +617,7 @@ static int solve_reduced(mpcqp_handle *h, hipStream_t s) {
   else rc = mpcqp_update(in, d.Pr, d.nnzPr, d.qr, d.nr, d.Ar, d.nnzAr, d.lr, d.mr, d.ur, d.mr, MPCQP_MEM_DEVICE);
   if (rc) return rc;
   if (h->st.warm_start && h->io.x0 && h->io.y0) {
-    if (!h->rx0) { if ((rc = dalloc(h, &h->rx0, (size_t)h->batch * d.nr)) || (rc = dalloc(h, &h->ry0, (size_t)h->batch * std::max(d.mr, 1)))) return rc; }
+    if (!h->rx0) return fail(MPCQP_ERR_STATE, "warm start on a reduced handle: settings.warm_start must be set when the handle is created");
     hipLaunchKernelGGL(mpcqp_red_gather_kernel, dim3(h->batch), dim3(256), 0, s, d, h->io.x0, h->io.y0, h->rx0, h->ry0);
     HIPCHK(hipGetLastError());
     if ((rc = mpcqp_warm_start(in, h->rx0, h->ry0, MPCQP_MEM_DEVICE))) return rc;
@@ -888,6 +892,7 @@ void mpcqp_destroy(mpcqp_handle *h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+  if (h->ev0r) (void)hipEventDestroy(h->ev0r);
   for (int i = 0; i < mpcqp_handle::NPIPE; i++) if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);
   if (h->pipe_copy) (void)hipStreamDestroy(h->pipe_copy);
   for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);

@@ -493,6 +493,11 @@ inline TilePlan build_tile_plan(const Plan &pl, int n, int m, const int *Ap, con
 }
 
 // workspace layout per QP, in doubles; every section starts on a 16-double (128 B) boundary
+// INVARIANT the resident kernels rely on: the slab is zeroed once, at mpcqp_create, and inside the T region a kernel only ever writes the
+// structural non-zeros (positions tpos >= 0); the other entries of the T tiles and the extra zero tile behind them stay 0 for the life of the
+// handle (the on-chip assembly reads that zero tile unconditionally: oc_asm_records).  The streaming kernel rewrites T[0 .. nT) completely and
+// never reads the zero tile.  The same holds for the zero tile behind the dense A tiles (TilePlan).  A kernel that wants scratch space in the
+// slab must not take it from T.
 struct WsLayout {
   long ellA = 0, ellAt = 0, ellP = 0, Lf = 0, Lb = 0, T = 0, l = 0, u = 0, D = 0, E = 0, dx = 0, dy = 0, Zg = 0, Yg = 0, stride = 0;
   long tile = 0, ellAr = 0, ellAtr = 0;      // dense tiles of A + the remainder ELL values (on-chip kernels with a TilePlan), behind everything else
