@@ -59,7 +59,7 @@ for a, b in (("bench_gpus2.json", "r03_bench_gpus2_share_gpu_rehearsal.json"), (
         txt = open(p).read().strip()
         try:
             cand = [l[l.index("{"):] for l in txt.splitlines() if "{" in l]
-            json.dump(json.loads(txt) if txt.startswith("[") else json.loads(cand[-1]), open(os.path.join(DST, b), "w"), indent=1)
+            json.dump(json.loads(txt) if txt.startswith("[\n") else json.loads(cand[-1]), open(os.path.join(DST, b), "w"), indent=1)
         except ValueError:
             print("skipped", a, file=sys.stderr)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("hbm_bytes_per_launch", "traffic_over_algorithmic", "kernel_ms_rocprof", "L2_hit_rate")} for k, v in summary.items() if k != "_doc"}, indent=1))
