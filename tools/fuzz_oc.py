@@ -2,12 +2,14 @@
 """Randomised GPU-vs-oracle sweep of the on-chip mode (MPCQP_VARIANT=oc4) over stage-OCP patterns: random state / input sizes, horizons,
 weights, nonlinear dynamics and iterates -- block tridiagonal + arrow patterns with single and twisted chains, phantom slots, hubs that
 share their block with the last frame.  Sizes the instance does not take (ERR_LIMIT) are counted and skipped.  Each case: a cold solve
-and a kept-workspace solve (new q, shifted bounds), against the oracle's.  usage: python tools/fuzz_oc.py [n_cases] [seed0]"""
+and a kept-workspace solve (new q, shifted bounds), against the oracle's.  usage: python tools/fuzz_oc.py [n_cases] [seed0] [oc4|oc8]
+(oc8: the eight-wave instances for long chains -- horizons drawn so that the chain part is 21 ... 56 blocks)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MPCQP_VARIANT"] = "oc4"
+FAMILY = sys.argv[3] if len(sys.argv) > 3 else "oc4"
+os.environ["MPCQP_VARIANT"] = FAMILY
 import numpy as np
 
 from optimal_control_problem_amd import _lib, models
@@ -20,6 +22,8 @@ tight = soft = bad = skipped = 0
 for c in range(ncase):
     rng = np.random.default_rng(5000 + seed0 + c)
     nx = int(rng.integers(2, 13)); nu = int(rng.integers(1, 5)); N = int(rng.integers(4, 26)); B = int(rng.integers(1, 6))
+    if FAMILY == "oc8":      # 21 ... 56 chain blocks of 16 variables
+        N = int(rng.integers((21 * 16) // (nx + nu) + 1, (56 * 16) // (nx + nu) + 1)); B = int(rng.integers(1, 4))
     Am = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx)); Bm = 0.3 * rng.normal(size=(nx, nu)); w = rng.normal(size=nx)
 
     class M(models.StageOCP):
@@ -40,7 +44,7 @@ for c in range(ncase):
         if e.code == _lib.ERR_LIMIT:
             skipped += 1; continue
         raise
-    assert qp.plan_info()["variant"] == 204
+    assert qp.plan_info()["variant"] == (208 if FAMILY == "oc8" else 204)
     qp.keep_workspace(True)
     pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
     q2 = ls.q * 1.2 + 0.05 * rng.normal(size=ls.q.shape); sh = 0.02 * rng.normal(size=ls.l.shape)

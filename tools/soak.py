@@ -15,7 +15,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 cases = [("quadrotor", 20, 8192, None), ("quadrotor", 20, 256, None), ("cartpole", 30, 8192, None), ("double_integrator", 20, 4096, None),
          ("quadrotor", 50, 2048, None), ("quadrotor", 10, 4096, None), ("cartpole", 50, 4096, None), ("cartpole", 20, 4096, None), ("double_integrator", 10, 8192, None),
          ("quadrotor", 10, 4096, "res4"), ("cartpole", 30, 4096, "res8"), ("quadrotor", 20, 2048, "stream"),
-         ("quadrotor", 12, 4096, "oc4"), ("cartpole", 30, 4096, "oc4"), ("quadrotor", 20, 8192, "gres4")]
+         ("quadrotor", 12, 4096, "oc4"), ("cartpole", 30, 4096, "oc4"), ("quadrotor", 20, 8192, "gres4"),
+         ("quadrotor", 50, 2048, "oc8"), ("cartpole", 100, 4096, "oc8"), ("quadrotor", 30, 2048, "oc8")]
 bad = 0
 for name, N, B, variant in cases:
     if variant: os.environ["MPCQP_VARIANT"] = variant
