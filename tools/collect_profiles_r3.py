@@ -33,7 +33,7 @@ for tag, (name, N, B) in WL.items():
         m = re.match(r"(\S+) launches (\d+) mean (\S+) .* kernel \['void (mpcqp_res_kernel<[^>]*>)", line)
         if m:
             vals[m.group(1)] = float(m.group(3)); kernel = m.group(4); launches = int(m.group(2))
-    ks = glob.glob(os.path.join(SRC, "kstats_%s" % tag, "*", "*kernel_stats.csv"))[0]
+    ks = max(glob.glob(os.path.join(SRC, "kstats_%s" % tag, "*", "*kernel_stats.csv")), key=os.path.getmtime)      # (the newest pass)
     shutil.copy(ks, os.path.join(DST, "r03_final_%s_kernel_stats.csv" % tag))
     row = [r for r in csv.DictReader(open(ks)) if "mpcqp_res_kernel" in r["Name"]][0]
     hbm = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
