@@ -140,10 +140,12 @@ constexpr int OC_NG = 5, OC_NH = 3;
 constexpr long OC_LDS_MAX = 80 * 1024;      // two workgroups per CU
 // Long chains (more than 20 chain blocks: quadrotor N > 20, cart-pole N > 60): eight waves per QP, one workgroup per CU -- the whole LDS and
 // 8 x 256 VGPRs for one factor.  Two instances: up to 32 chain blocks with every hub block in registers (cart-pole N = 100: 62 KB of chain
-// blocks + 36 KB of vectors in LDS), and up to 56 with five hub blocks per wave in registers, the rest in LDS, and z, y in the slab
-// (quadrotor N = 50: 49 chain blocks + 10 hub blocks + the hub's inverse = 120 KB, 35 KB of vectors)
+// blocks + 36 KB of vectors in LDS), and up to 56 with seven positions per wave, G_p and every hub block (both orientations) in registers --
+// 168 resident VGPRs -- and only the chain blocks and the hub's inverse in LDS (quadrotor N = 50: 50 blocks = 100 KB + 57 KB of vectors and
+// tables = 159,880 B).  (Measured against <NG 7, NH 5> with z, y in the slab, 157,832 B and 136 resident VGPRs: 35.5 against 35.9 ms and an
+// eighth less HBM traffic -- the slab vectors cost more than the extra spills.)
 struct Oc8Inst { int ng, nh; bool zyg; };
-constexpr Oc8Inst OC8_INST[2] = {{4, 4, false}, {7, 5, true}};
+constexpr Oc8Inst OC8_INST[2] = {{4, 4, false}, {7, 7, false}};
 constexpr long OC8_LDS_MAX = 160 * 1024;
 constexpr int OC8_MAX_CHAIN = 64;           // (oc_ldl keeps the chain's block ids one per lane)
 

@@ -208,10 +208,11 @@ def _run_oc8(ls, NG, NH, zyg, b=0, seed=0, ldl=1):
     return rc, dict(nbc=info[0], has_hub=info[1], junc=info[2], nlds=info[3], nhr=info[4], lds=info[5], LE=info[6], LF=info[7])
 
 
-@pytest.mark.parametrize("name,N,inst,expect", [("quadrotor", 50, (7, 5, 1), dict(nbc=50, has_hub=1, junc=1, nlds=60, LE=24, LF=26)),       # BASELINE config 3: 49 chain + 10 hub blocks + the hub's inverse in LDS
+@pytest.mark.parametrize("name,N,inst,expect", [("quadrotor", 50, (7, 7, 0), dict(nbc=50, has_hub=1, junc=1, nlds=50, LE=24, LF=26)),       # BASELINE config 3 as mpcqp_create takes it: 49 chain blocks + the hub's inverse in LDS, every hub block in registers
+                                                ("quadrotor", 50, (7, 5, 1), dict(nbc=50, has_hub=1, junc=1, nlds=60)),                      # (the alternative split: ten hub blocks in LDS, z / y in the slab)
                                                 ("cartpole", 100, (4, 4, 0), dict(nbc=32, has_hub=1, junc=1, nlds=32, LE=15, LF=17)),        # config 4: padded twist, two chains instead of one of 31
-                                                ("quadrotor", 30, (4, 4, 0), dict(nbc=30, junc=1)), ("quadrotor", 40, (7, 5, 1), dict(nbc=40)),
-                                                ("cartpole", 150, (7, 5, 1), dict(nbc=47, junc=1)), ("double_integrator", 100, (4, 4, 0), dict(nbc=19))])
+                                                ("quadrotor", 30, (4, 4, 0), dict(nbc=30, junc=1)), ("quadrotor", 40, (7, 7, 0), dict(nbc=40)),
+                                                ("cartpole", 150, (7, 7, 0), dict(nbc=47, junc=1)), ("double_integrator", 100, (4, 4, 0), dict(nbc=19))])
 @pytest.mark.parametrize("ldl", [0, 1])
 def test_onchip_long_chain_plan_emulated(built, name, N, inst, expect, ldl):
     """the eight-wave instances' tables (kernel_onchip.hpp with NW = 8: per-wave partial sums 1 .. 8 and the zero block behind them, positions
@@ -247,11 +248,11 @@ def test_tile_plan_products(built, name, N, order, ntile):
 
 def test_onchip_long_chain_plan_limits(built):
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=57)          # 57 chain blocks: more than seven positions per wave
-    assert _run_oc8(ls, 7, 5, 1)[0] == 5
+    assert _run_oc8(ls, 7, 7, 0)[0] == 5
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=40)          # 40 positions do not fit the <4, 4> instance
-    assert _run_oc8(ls, 4, 4, 0)[0] == 5 and _run_oc8(ls, 7, 5, 1)[0] == 0
+    assert _run_oc8(ls, 4, 4, 0)[0] == 5 and _run_oc8(ls, 7, 7, 0)[0] == 0
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=56)          # the tables exist, but the LDS of one CU does not hold it: mpcqp_create keeps the global-block kernel
-    rc, info = _run_oc8(ls, 7, 5, 1)
+    rc, info = _run_oc8(ls, 7, 7, 0)
     assert rc == 0 and info["lds"] > 160 * 1024
 
 
