@@ -328,6 +328,8 @@ class OptimalControlProblem:
         """generate + compile the local-system evaluation for the GPU (the reference's genCode writes C for the NLP solver and
         shells out to gcc, OptimalControlProblem.cpp:263-287,602-640); returns the path of the shared library"""
         from . import codegen
+        if getattr(self, "generalPath_", False):
+            raise NotImplementedError("gen_code compiles the stage pattern for the device; this problem takes the general path (%s)" % self.generalPathReason_)
         model = self.model_ if self.model_ is not None else self._compile_stage_model()
         h_lo, h_hi = model.path_bounds() if model.nh else (None, None)
         tape = codegen.trace(model.F, model.nx, model.nu, model.hfun if model.nh else None, model.nh, h_lo[0] if model.nh else None, h_hi[0] if model.nh else None,
@@ -473,8 +475,9 @@ class OptimalControlProblem:
         reference = np.asarray(reference, float).reshape(self.batch, -1)
         if frame.shape[1] != cfg.getFrameSize():
             raise ValueError("State dimension mismatch: received %d, expected %d" % (frame.shape[1], cfg.getFrameSize()))      # :79-84
-        if reference.shape[1] != self.reference_.size:
-            raise ValueError("Reference dimension mismatch: received %d, expected %d" % (reference.shape[1], self.reference_.size))  # :85-90
+        rsize = self.reference_.size if self.reference_ is not None else 0           # (no setReference(): an empty parameter vector, like an empty SX)
+        if reference.shape[1] != rsize:
+            raise ValueError("Reference dimension mismatch: received %d, expected %d" % (reference.shape[1], rsize))  # :85-90
         lbx = np.tile(np.concatenate(cfg.getLowerBounds()), (self.batch, 1))
         ubx = np.tile(np.concatenate(cfg.getUpperBounds()), (self.batch, 1))
         fs = cfg.getFrameSize()
@@ -498,7 +501,7 @@ class OptimalControlProblem:
         ng = sum(len(b) for b in self.constraintLowerBounds_)
         nv = self.OCPConfigPtr_.getVariables()
         ok = arg["lbg"].shape[1] == ng and arg["ubg"].shape[1] == ng and arg["lbx"].shape[1] == nv and \
-            arg["ubx"].shape[1] == nv and arg["x0"].shape[1] == nv and arg["p"].shape[1] == self.reference_.size
+            arg["ubx"].shape[1] == nv and arg["x0"].shape[1] == nv and arg["p"].shape[1] == (self.reference_.size if self.reference_ is not None else 0)
         return bool(ok)
 
     def getOptimalTrajectory(self):

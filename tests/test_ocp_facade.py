@@ -339,3 +339,26 @@ def test_general_path_skip_coupling_on_gpu(built):
         assert ocp.generalPath_
         out.append(ocp.computeOptimalTrajectory(frame, ref))
     assert np.abs(out[0] - out[1]).max() < 1e-6
+
+
+def test_general_path_without_a_reference_vector_and_gen_code(built):
+    """no setReference(): the parameter vector is empty (np = 0), as with an SX that was never assigned; genCode() on a problem that took the
+    general path says why it cannot compile it for the device"""
+    from tests.support.oracle_backend import OracleCuCaQP
+
+    class P(OptimalControlProblem):
+        def deployConstraintsAndAddCost(self):
+            self.addScalarCost(General(lambda X, p: (X[2] - 1.0) ** 2 + (X[3] + 2.0) ** 2 + X[2] * X[3]))
+            self.addInequalityConstraint("sum", [-np.inf], General(lambda X, p: [X[2] + X[3]], 1), [0.5])
+
+    node = yaml.safe_load(TESTCPP_YAML % (2, "[-10.0, -10.0]", "[10.0, 10.0]"))["optimal_control_problem"]
+    ocp = P(node, batch=1, qp_solver=OracleCuCaQP(batch=1))
+    ocp.deployConstraintsAndAddCost(); ocp.genSolver()
+    assert ocp.generalPath_ and ocp.model_.np == 0
+    x = ocp.computeOptimalTrajectory(np.zeros((1, 2)), np.zeros((1, 0)))
+    # min (a - 1)^2 + (b + 2)^2 + a b  s.t. a + b <= 0.5: the unconstrained optimum (8/3, -10/3) is feasible
+    assert np.abs(x[0, 2:] - np.array([8.0 / 3, -10.0 / 3])).max() < 5e-3
+    with pytest.raises(NotImplementedError, match="general path"):
+        ocp.genCode()
+    with pytest.raises(ValueError, match="Reference dimension mismatch"):
+        ocp.computeOptimalTrajectory(np.zeros((1, 2)), np.zeros((1, 1)))
