@@ -976,3 +976,43 @@ def test_experimental_tile_sweeps_vs_oracle(built, monkeypatch, name, B, N):
     monkeypatch.delenv("MPCQP_TILES")
     qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai); info = qp.plan_info(); qp.close()
     assert info["tiles"] == 0                                                # default: ELL sweeps
+
+
+@pytest.mark.parametrize("name,B,N", [("quadrotor", 6, 30), ("cartpole", 6, 100)])
+def test_onchip_long_chains_warm_start_rho_and_refused_instances(built, name, B, N):
+    """the interface features on the eight-wave on-chip instances (the default for these sizes): warm start, per-instance starting rho, an
+    instance with crossed bounds refused while the others solve, an instance made primal infeasible reporting its certificate, the dispatch
+    hint changing no result"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    cold = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings())
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, warm_start=1)
+    assert qp.plan_info()["variant"] == 208
+    # warm start + starting rho
+    rho0 = cold["rho"].copy(); rho0[::2] = 0.0
+    ref = pat.solve(ls.P, ls.q, ls.A, ls.l, ls.u, orc.default_settings(warm_start=1), x0=cold["x"], y0=cold["y"], rho0=rho0)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.warm_start(cold["x"], cold["y"]); qp.set_rho(rho0); qp.solve(); got = qp.get()
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    _close(got, ref, "x"); _close(got, ref, "y")
+    # the same solve again, now dispatched by the hint of the first: bitwise the same
+    qp.solve(); again = qp.get()
+    assert np.array_equal(again["x"], got["x"]) and np.array_equal(again["iters"], got["iters"])
+    qp.close()
+    # instance 1: crossed bounds on one row (refused); instance 2: the second frame's first state boxed away from anything the pinned first
+    # frame can reach in one step (primal infeasible)
+    l2, u2 = ls.l.copy(), ls.u.copy()
+    l2[1, mdl.np + 3] = 1.0; u2[1, mdl.np + 3] = -1.0
+    row = mdl.np + mdl.f                      # the bound row of frame 1, state 0
+    l2[2, row] = 50.0; u2[2, row] = 60.0
+    ref2 = pat.solve(ls.P, ls.q, ls.A, l2, u2, orc.default_settings())
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    qp.update(ls.P, ls.q, ls.A, l2, u2); qp.solve(); got2 = qp.get(); qp.close()
+    assert got2["status"][1] == 11 and got2["iters"][1] == 0 and np.isnan(got2["x"][1]).all()          # MPCQP_UNSOLVED: refused
+    keep = np.arange(B) != 1
+    assert (got2["status"][keep] == ref2["status"][keep]).all(), (got2["status"], ref2["status"])
+    assert ref2["status"][2] in (3, 4)                                                                   # the oracle certifies infeasibility
+    ok = keep & np.isfinite(ref2["x"]).all(axis=1)
+    assert (got2["iters"][ok] == ref2["iters"][ok]).all()
+    assert np.abs(got2["x"][ok] - ref2["x"][ok]).max() <= 1e-6 * (1 + np.abs(ref2["x"][ok]).max())
