@@ -278,6 +278,53 @@ int mpcqp_stage_merit(mpcqp_stage *s, int batch, const double *p, const double *
 int mpcqp_stage_step(mpcqp_stage *s, int batch, double alpha, const double *dw, double *x, double *step_max,
                      const int *status, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Structured stage form: the same QP, given by its stage blocks instead of CSC value arrays.
+ *
+ * The reference only ever produces OCP-structured QPs: the decision vector is the stage-interleaved list of frames
+ * [s_k; u_k] (src/OCP_config/OCPConfig.cpp:29-46,102) behind a parameter block p, and the local QP has w = [p; frames] and rows
+ * [p; frames; g] (src/sqp_solver/SQPOptimizationSolver.cpp:47-77).  A caller that has the blocks -- an LTV / linearised MPC that
+ * never went through CasADi -- would have to scatter them into CSC arrays itself to call mpcqp_update.  Here it names the stage
+ * dimensions once and hands over, per instance (instance-major, dense, row-major):
+ *     H   [N][f][f]       Hessian block of frame k, f = nx + nu (symmetric; both triangles are read as given)
+ *     Hp  [N][np][f]      P[p, frame_k]  (its transpose fills P[frame_k, p]);   Hpp [np][np]  P[p, p]      (both NULL when np = 0)
+ *     AB  [N-1][nx][f]    [A_k B_k] of  s_{k+1} = A_k s_k + B_k u_k + c_k : dynamics row block k reads
+ *                         lg_k <= s_{k+1} - A_k s_k - B_k u_k <= ug_k  (an equality when lg_k = ug_k = c_k), the sign convention of the
+ *                         reference's rows (+1 on s_{k+1}, -dF/d[s_k; u_k]; compare mpcqp_stage_eval above)
+ *     q [n], l [m], u [m] as in mpcqp_update: n = np + N f in the order [p; frames], m = n + (N - 1) nx in the order
+ *                         [p; frames; dynamics] (the identity rows carry the box bounds; the reference pins p with l = u)
+ * The QP is the one mpcqp_create / mpcqp_update would get for the CSC pattern mpcqp_stageqp_pattern returns -- for np = nx and dense
+ * masks exactly mpcqp_stage_pattern's -- and it runs on an ordinary handle on that pattern: blocks and CSC arrays holding the same
+ * numbers give bitwise the same x, y, z, status and iteration counts (tests/test_gpu_stageqp.py).  One gather kernel per update writes
+ * the CSC value arrays (algorithmic bytes: blocks in, nnz(P) + nnz(A) values out); the ADMM kernels are not aware of this form.
+ * Optional masks keep structural zeros out of the pattern (a diagonal tracking cost, a sparse Jacobian): entries masked out are not
+ * read.  np = 0: a plain LQ-structured QP without the reference's parameter block. */
+typedef struct mpcqp_stageqp_dims {
+  int N;                            /* frames, >= 2 */
+  int nx, nu;                       /* frame k = [s_k (nx); u_k (nu)] */
+  int np;                           /* leading parameter block (0 = none) */
+  const unsigned char *cost_mask;   /* optional [(f + np)^2] row-major over the local variables [s; u; p]: which entries of H_k, Hp_k, Hpp exist
+                                       (symmetric, diagonal set; the same for every frame); NULL = dense blocks */
+  const unsigned char *dyn_mask;    /* optional [nx * f] row-major: which entries of [A_k B_k] exist; NULL = dense */
+} mpcqp_stageqp_dims;
+
+typedef struct mpcqp_stageqp mpcqp_stageqp;
+
+/* CSC pattern of the stage form (host only; no GPU needed): sizes4 = {n, m, nnz(P), nnz(A)}; any of the arrays may be NULL (query the
+ * sizes first).  P has both triangles, rows ascending inside a column -- what CasADi hands CuCaQP::setHessianMatrix. */
+int mpcqp_stageqp_pattern(const mpcqp_stageqp_dims *d, int *sizes4, int *P_colptr, int *P_rowidx, int *A_colptr, int *A_rowidx);
+/* mpcqp_create on that pattern plus the maps and value arrays of the gather kernel */
+int mpcqp_stageqp_create(const mpcqp_stageqp_dims *d, int batch, const mpcqp_settings *settings, mpcqp_stageqp **out);
+/* the ordinary handle underneath: mpcqp_solve / _get / _warm_start / _set_rho / _keep_workspace / _update_vectors / _plan_info apply to it
+ * (x, y, z come back in the orders given above).  Owned by the mpcqp_stageqp: do not destroy it. */
+mpcqp_handle *mpcqp_stageqp_handle(mpcqp_stageqp *s);
+/* mpcqp_update in blocks.  mem = MPCQP_MEM_DEVICE: the gather kernel is queued on `stream` -- the stream of the mpcqp_solve calls on this
+ * handle -- and q, l, u are borrowed until that solve has completed, like in mpcqp_update; the block arrays are free once the kernel
+ * has run.  mem = MPCQP_MEM_HOST: everything is copied before the call returns. */
+int mpcqp_stageqp_update(mpcqp_stageqp *s, const double *H, const double *Hp, const double *Hpp, const double *AB,
+                         const double *q, const double *l, const double *u, int mem, void *stream);
+void mpcqp_stageqp_destroy(mpcqp_stageqp *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ Importing the package never touches the GPU; the first compute call loads libmpc
 the library or a gfx950 device is missing (there is no CPU fallback)."""
 from . import models  # noqa: F401
 
-__all__ = ["models", "BatchQP", "CuCaQP", "SQPOptimizationSolver", "DeviceSQPOptimizationSolver", "StageEvaluator",
+__all__ = ["models", "BatchQP", "StageQP", "CuCaQP", "SQPOptimizationSolver", "DeviceSQPOptimizationSolver", "StageEvaluator",
            "OptimalControlProblem", "OCPConfig"]
 
 
@@ -13,6 +13,9 @@ def __getattr__(name):
     if name == "BatchQP":
         from .batch_qp import BatchQP
         return BatchQP
+    if name == "StageQP":
+        from .stage_qp import StageQP
+        return StageQP
     if name == "CuCaQP":
         from .cucaqp import CuCaQP
         return CuCaQP

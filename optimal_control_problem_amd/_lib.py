@@ -18,7 +18,8 @@ EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_create_tuned", "mpcq
            "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms",
            "mpcqp_plan_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
            "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_set_path_bounds", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
-           "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step"]
+           "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step",
+           "mpcqp_stageqp_pattern", "mpcqp_stageqp_create", "mpcqp_stageqp_handle", "mpcqp_stageqp_update", "mpcqp_stageqp_destroy"]
 
 
 class Settings(C.Structure):
@@ -40,7 +41,7 @@ class MpcqpError(RuntimeError):
 def build(force=False):
     """Compile libmpcqp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "kernels_common.hpp", "kernel_stream.hpp", "kernel_onchip.hpp", "kernel_resident.hpp", "kernels_util.hpp", "reduced.hpp", "plan.hpp", "stage_eval.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
+    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "kernels_common.hpp", "kernel_stream.hpp", "kernel_onchip.hpp", "kernel_resident.hpp", "kernels_util.hpp", "reduced.hpp", "plan.hpp", "stage_eval.hip", "stageqp.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
     if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps):
         subprocess.check_call(["make", "-C", src, "-B", "../libmpcqp.so"], stdout=subprocess.DEVNULL)
     return SO_PATH
@@ -87,6 +88,13 @@ def lib():
         L.mpcqp_plan_info.argtypes = [vp, vp]
         L.mpcqp_debug_scaling.argtypes = [vp, C.c_int, dp, dp, dp]
         L.mpcqp_debug_blockops.argtypes = [dp, dp, dp, dp, dp, dp, vp]
+        L.mpcqp_stageqp_pattern.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.mpcqp_stageqp_create.argtypes = [vp, C.c_int, C.POINTER(Settings), C.POINTER(vp)]
+        L.mpcqp_stageqp_handle.argtypes = [vp]
+        L.mpcqp_stageqp_handle.restype = vp
+        L.mpcqp_stageqp_update.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp, C.c_int, vp]
+        L.mpcqp_stageqp_destroy.argtypes = [vp]
+        L.mpcqp_stageqp_destroy.restype = None
         _LIB = L
     return _LIB
 

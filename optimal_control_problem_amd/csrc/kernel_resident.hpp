@@ -7,9 +7,10 @@
 // HBM is touched per iteration only for the ELL sweeps of A / A' (L2-resident per-QP slabs) and l, u.
 // =========================================================================================================
 #ifdef MPCQP_TIMING
-#define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[16] = {0}
+#define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[16] = {0}; const unsigned long long ts_first = ts_last, ts_rt0 = __builtin_amdgcn_s_memrealtime()
 #define TS(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[k] += t_ - ts_last; ts_last = t_; } while (0)
-#define TS_STORE(ptr) do { if (tid == 0 && (ptr)) for (int k_ = 0; k_ < 16; k_++) (ptr)[16L * b + k_] = (long long)ts_acc[k_]; } while (0)
+#define TS_STORE(ptr) do { if (tid == 0 && (ptr)) { for (int k_ = 0; k_ < 16; k_++) (ptr)[16L * b + k_] = (long long)ts_acc[k_]; \
+    if (b == 0) { (ptr)[16L * gridDim.x + 126] = (long long)(__builtin_amdgcn_s_memtime() - ts_first); (ptr)[16L * gridDim.x + 127] = (long long)(__builtin_amdgcn_s_memrealtime() - ts_rt0); } } } while (0)     /* (the last two: what s_memtime counts, against the constant 100 MHz counter) */
 #else
 // (phase boundaries stay scheduling boundaries in the product build: the timing build, whose time stamps make them so, was 6.5 % FASTER on the
 // 12-state quadrotor -- without them the compiler moves loads of the next phase up into a phase whose registers are all spoken for)

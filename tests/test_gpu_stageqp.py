@@ -1,0 +1,113 @@
+"""Structured stage form on the GPU (include/mpcqp.h "Structured stage form", csrc/stageqp.hip): a QP given by its stage blocks and the
+same QP given in CSC arrays are the same run -- bit for bit when the numbers are the same -- and both agree with the oracle."""
+import numpy as np
+import pytest
+
+from optimal_control_problem_amd import _lib, models
+from optimal_control_problem_amd.batch_qp import BatchQP
+from optimal_control_problem_amd.stage_qp import StageQP, blocks_from_dense
+from tests.support import problems
+from tests.support import stage_blocks as sb
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("x", "y", "z", "status", "iters", "obj", "prim_res", "dual_res", "rho")
+
+
+def _same(a, b):
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("name,N,B", [("quadrotor", 20, 24), ("quadrotor", 50, 6), ("cartpole", 100, 6), ("double_integrator", 20, 33)])
+def test_blocks_and_csc_are_the_same_run(built, name, N, B):
+    """the BASELINE workloads in the reference's formulation (parameter block, diagonal tracking cost, Jacobian structure): handed over in
+    blocks they give bitwise what the CSC arrays give -- same pattern (tests/test_stageqp.py), same numbers, same kernel instance --
+    and that is what the oracle gives (status, iteration counts, x to 1e-6)"""
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    nx, nu = mdl.nx, mdl.nu
+    cm, dm = sb.masks_of(ls, N, nx, nu, nx)
+    Pd, Ad = sb.dense_batch(ls)
+    H, Hp, Hpp, AB = blocks_from_dense(Pd, Ad, N, nx, nu, nx)
+    sq = StageQP(N, nx, nu, B, np_=nx, cost_mask=cm, dyn_mask=dm)
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert sq.plan_info() == qp.plan_info()
+    sq.update_blocks(H, Hp, Hpp, AB, ls.q, ls.l, ls.u); sq.solve(); got = sq.get()
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); want = qp.get()
+    _same(got, want)
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6 * (1 + np.abs(ref["x"]).max())
+    # device-resident blocks, the gather kernel and the solve on one stream
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, order="C")).to(dev)
+    st = torch.cuda.Stream(device=dev)
+    tens = [t(a) for a in (H, Hp, Hpp, AB, np.broadcast_to(ls.q, (B, ls.n)), np.broadcast_to(ls.l, (B, ls.m)), np.broadcast_to(ls.u, (B, ls.m)))]
+    torch.cuda.synchronize(dev)
+    sq.update_blocks(*tens, stream=st.cuda_stream); sq.solve(stream=st.cuda_stream); got2 = sq.get()
+    _same(got2, want)
+    # the handle underneath is an ordinary one: a kept workspace and new vectors
+    sq.keep_workspace(True)
+    sq.update_blocks(H, Hp, Hpp, AB, ls.q, ls.l, ls.u); sq.solve()
+    q2 = np.broadcast_to(ls.q, (B, ls.n)) * 1.01
+    sq.update_vectors(q2, ls.l, ls.u); sq.solve(); got3 = sq.get()
+    qp.keep_workspace(True)
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); qp.update_vectors(q2, ls.l, ls.u); qp.solve()
+    _same(got3, qp.get())
+    sq.close(); qp.close()
+
+
+def test_dense_blocks_without_masks(built):
+    """no masks: the pattern carries the blocks' structural zeros as explicit entries -- an equivalent QP on a different plan; same answer
+    within the tolerance of the tightest parity tests, same iteration counts"""
+    N, B = 10, 12
+    mdl, ls, _ = models.make_workload("quadrotor", B, N=N)
+    nx, nu = mdl.nx, mdl.nu
+    Pd, Ad = sb.dense_batch(ls)
+    H, Hp, Hpp, AB = blocks_from_dense(Pd, Ad, N, nx, nu, nx)
+    sq = StageQP(N, nx, nu, B, np_=nx)
+    assert sq.nnzP > len(ls.Pi) and sq.nnzA >= len(ls.Ai)
+    sq.update_blocks(H, Hp, Hpp, AB, ls.q, ls.l, ls.u); sq.solve(); got = sq.get(); sq.close()
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6 * (1 + np.abs(ref["x"]).max())
+
+
+@pytest.mark.parametrize("N,nx,nu,B", [(12, 4, 2, 9), (30, 6, 3, 5), (2, 1, 0, 3)])
+def test_ltv_without_parameter_block_vs_oracle(built, N, nx, nu, B):
+    """np = 0: a plain LQ-structured QP (dense stage Hessians, time-varying dynamics).  Against the generic CSC path (bitwise) and the oracle"""
+    H, AB, q, l, u, Pd, Ad = sb.random_ltv(N, nx, nu, B, seed=N)
+    sq = StageQP(N, nx, nu, B)
+    sq.update_blocks(H, None, None, AB, q, l, u); sq.solve(); got = sq.get()
+    P = sb.csc_values(Pd, sq.Pp, sq.Pi); A = sb.csc_values(Ad, sq.Ap, sq.Ai)
+    qp = BatchQP(sq.n, sq.m, B, sq.Pp, sq.Pi, sq.Ap, sq.Ai)
+    qp.update(P, q, A, l, u); qp.solve(); want = qp.get(); qp.close()
+    _same(got, want)
+    ls = models.LocalSystem(sq.n, sq.m, sq.Pp, sq.Pi, sq.Ap, sq.Ai, P, q, A, l, u)
+    ref = problems.oracle_solve(ls)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-6 * (1 + np.abs(ref["x"]).max())
+    # the dynamics hold at the solution: s_{k+1} - A_k s_k - B_k u_k = c_k to the termination tolerance
+    f = nx + nu
+    x = got["x"].reshape(B, N, f)
+    for k in range(N - 1):
+        r = x[:, k + 1, :nx] - np.einsum("brc,bc->br", AB[:, k], x[:, k]) - l[:, sq.n + k * nx:sq.n + (k + 1) * nx]
+        assert np.abs(r).max() < 5e-3
+    sq.close()
+
+
+def test_stageqp_argument_errors(built):
+    sq = StageQP(4, 2, 1, 3, np_=2)
+    H = np.zeros((3, 4, 3, 3)); Hp = np.zeros((3, 4, 2, 3)); Hpp = np.zeros((3, 2, 2)); AB = np.zeros((3, 3, 2, 3))
+    q = np.zeros((3, sq.n)); l = np.zeros((3, sq.m)); u = np.zeros((3, sq.m))
+    with pytest.raises(TypeError):
+        sq.update(None, q, None, l, u)
+    with pytest.raises(ValueError):
+        sq.update_blocks(H[:, :3], Hp, Hpp, AB, q, l, u)                      # a frame short
+    with pytest.raises(ValueError):
+        sq.update_blocks(H, None, None, AB, q, l, u)                          # parameter blocks missing
+    with pytest.raises(_lib.MpcqpError) as e:
+        sq.solve()                                                            # nothing was handed over yet
+    assert e.value.code == _lib.ERR_STATE
+    sq.close()

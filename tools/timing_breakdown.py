@@ -38,6 +38,8 @@ it = got["iters"].mean()
 print("  per ADMM iteration: At %.0f, solve %.0f, A+x %.0f cycles" % (out[:, 4].mean() / it, out[:, 5].mean() / it, out[:, 6].mean() / it))
 
 tr = raw[batch * 16:]
+if tr[127] > 0:
+    print("  workgroup 0: %d s_memtime ticks in %d ticks of the constant 100 MHz counter: s_memtime runs at %.0f MHz" % (tr[126], tr[127], 100.0 * tr[126] / tr[127]))
 if tr[0] > 0:
     print("  wave-0 solve: %d cycles; per segment (cycles, flags[T=1,SET=2,EACH=4,END=8,BAR=16,NOP=32], ops):" % (tr[1] - tr[0]))
     prev = tr[0]; out_ = []
