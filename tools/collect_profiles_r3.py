@@ -62,4 +62,8 @@ for a, b in (("bench_gpus2.json", "r03_bench_gpus2_share_gpu_rehearsal.json"), (
             json.dump(json.loads(txt) if txt.startswith("[\n") else json.loads(cand[-1]), open(os.path.join(DST, b), "w"), indent=1)
         except ValueError:
             print("skipped", a, file=sys.stderr)
+for a, b in (("stageqp_bench.txt", "r03_stageqp_bench.txt"), ("chain_stage_probe.txt", "r03_chain_stage_probe.txt")):
+    p = os.path.join(SRC, a)
+    if os.path.exists(p) and os.path.getsize(p) > 2:
+        open(os.path.join(DST, b), "w").writelines(l for l in open(p) if "amdgpu.ids" not in l)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("hbm_bytes_per_launch", "traffic_over_algorithmic", "kernel_ms_rocprof", "L2_hit_rate")} for k, v in summary.items() if k != "_doc"}, indent=1))

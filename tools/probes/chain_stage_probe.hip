@@ -132,8 +132,8 @@ static void run(const double *W, const double *c, const std::vector<double> &ref
   long long t; hipMemcpy(&t, tk, 8, hipMemcpyDeviceToHost);
   std::vector<double> h((NSTAGE + 1) * BS); hipMemcpy(h.data(), o, h.size() * 8, hipMemcpyDeviceToHost);
   double err = 0; for (int i = BS; i < (NSTAGE + 1) * BS; i++) err = fmax(err, fabs(h[i] - ref[i]));
-  printf("V%d %s: %.1f ns per stage by s_memtime (100 MHz), kernel %.1f ns per stage; max |t - reference| %.2e\n", V, noisy ? "7 other waves reading LDS" : "alone            ",
-         t * 10.0 / (double(reps) * NSTAGE), ms * 1e6 / (double(reps) * NSTAGE), err);
+  printf("V%d %s: %.1f s_memtime ticks per stage (the shader clock, 2.4 GHz), kernel %.1f ns per stage; max |t - reference| %.2e\n", V, noisy ? "7 other waves reading LDS" : "alone            ",
+         t / (double(reps) * NSTAGE), ms * 1e6 / (double(reps) * NSTAGE), err);
   hipFree(o); hipFree(tk);
 }
 

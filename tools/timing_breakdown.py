@@ -29,7 +29,7 @@ _lib.check(L.mpcqp_debug_timing(qp._h, raw.ctypes.data))
 names = ["load", "ruiz", "apply-scale+init", "factor(first)", "At pass", "schedule(solve)", "A pass + x", "check", "store",
          "oc:F1 chains", "oc:F2+F3 hub", "oc:B1 diag+hub", "f:rho/dvec/T", "f:assemble", "f:LDL", "f:LDL sweeps"]
 tot = out[:, :9].sum(axis=1).mean()
-print("variant", qp.plan_info()["variant"], "kernel %.2f ms for %d QPs, mean iters %.1f, mean cycles/QP %.0f (100 MHz ticks: %s)" % (
+print("variant", qp.plan_info()["variant"], "kernel %.2f ms for %d QPs, mean iters %.1f, mean cycles/QP %.0f (%s ticks: the shader clock)" % (
     ms, batch, got["iters"].mean(), tot, "s_memtime"))
 for k, nm in enumerate(names):
     if nm != "-" and out[:, k].mean() > 0:
