@@ -111,3 +111,45 @@ def test_stageqp_argument_errors(built):
         sq.solve()                                                            # nothing was handed over yet
     assert e.value.code == _lib.ERR_STATE
     sq.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_masks_blocks_vs_csc_and_oracle(built, seed):
+    """random stage dimensions, random symmetric cost mask over [s; u; p], random Jacobian mask: the blocks scattered by the library against the
+    same numbers scattered in NumPy (bitwise through the generic path) and against the oracle"""
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(3, 12)); nx = int(rng.integers(2, 6)); nu = int(rng.integers(1, 4)); npar = int(rng.choice([0, nx, 2])); B = int(rng.integers(2, 9))
+    f = nx + nu; nl = f + npar
+    cm = rng.random((nl, nl)) < 0.35; cm = cm | cm.T | np.eye(nl, dtype=bool)
+    dm = (rng.random((nx, f)) < 0.6) | np.eye(nx, f, dtype=bool)
+    n, m, Pp, Pi, Ap, Ai, Pm, Am = sb.numpy_pattern(N, nx, nu, npar, cm, dm)
+    # diagonally dominant P (convex), stable-ish dynamics; masked-out entries hold garbage that must not be read
+    H = rng.uniform(-0.3, 0.3, (B, N, f, f)); H = 0.5 * (H + H.transpose(0, 1, 3, 2)); H[:, :, np.arange(f), np.arange(f)] = nl + rng.random((B, N, f))
+    Hp = rng.uniform(-0.3, 0.3, (B, N, npar, f)) / N
+    Hpp = rng.uniform(-0.3, 0.3, (B, npar, npar)); Hpp = 0.5 * (Hpp + Hpp.transpose(0, 2, 1)); Hpp[:, np.arange(npar), np.arange(npar)] = nl + 1.0
+    AB = rng.uniform(-0.4, 0.4, (B, N - 1, nx, f)); AB[:, :, np.arange(nx), np.arange(nx)] += 1.0
+    Pd = np.zeros((B, n, n)); Ad = np.zeros((B, m, n))
+    Pd[:, :npar, :npar] = Hpp * cm[f:, f:]
+    Ad[:, np.arange(n), np.arange(n)] = 1.0
+    for k in range(N):
+        sl = slice(npar + k * f, npar + (k + 1) * f)
+        Pd[:, sl, sl] = H[:, k] * cm[:f, :f]; Pd[:, :npar, sl] = Hp[:, k] * cm[f:, :f]; Pd[:, sl, :npar] = (Hp[:, k] * cm[f:, :f]).transpose(0, 2, 1)
+        if k < N - 1:
+            Ad[:, n + k * nx:n + (k + 1) * nx, sl] = -AB[:, k] * dm
+            Ad[:, n + k * nx + np.arange(nx), npar + (k + 1) * f + np.arange(nx)] = 1.0
+    q = rng.normal(size=(B, n)); l = np.full((B, m), -2.0); u = np.full((B, m), 2.0)
+    l[:, :npar] = 0.0; u[:, :npar] = 0.0                                    # dp = 0 (reference SQPOptimizationSolver.cpp:117)
+    c = 0.1 * rng.normal(size=(B, (N - 1) * nx)); l[:, n:] = c; u[:, n:] = c
+    sq = StageQP(N, nx, nu, B, np_=npar, cost_mask=cm, dyn_mask=dm)
+    for got, want in ((sq.Pp, Pp), (sq.Pi, Pi), (sq.Ap, Ap), (sq.Ai, Ai)):
+        assert np.array_equal(got, want)
+    poison = lambda a, keep: np.where(keep, a, 1e300)                       # what the masks exclude is never touched
+    sq.update_blocks(poison(H, cm[:f, :f]), poison(Hp, cm[f:, :f]) if npar else None, poison(Hpp, cm[f:, f:]) if npar else None, poison(AB, dm), q, l, u)
+    sq.solve(); got = sq.get(); sq.close()
+    P = sb.csc_values(Pd, Pp, Pi); A = sb.csc_values(Ad, Ap, Ai)
+    qp = BatchQP(n, m, B, Pp, Pi, Ap, Ai); qp.update(P, q, A, l, u); qp.solve(); want = qp.get(); qp.close()
+    _same(got, want)
+    ref = problems.oracle_solve(models.LocalSystem(n, m, Pp, Pi, Ap, Ai, P, q, A, l, u))
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    fin = np.isfinite(ref["x"])
+    assert np.array_equal(np.isfinite(got["x"]), fin) and (not fin.any() or np.abs(got["x"][fin] - ref["x"][fin]).max() <= 1e-6 * (1 + np.abs(ref["x"][fin]).max()))

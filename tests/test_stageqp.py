@@ -63,3 +63,26 @@ def test_blocks_from_dense_round_trip(built):
     H, AB, q, l, u, Pd, Ad = sb.random_ltv(5, 3, 2, 2, 0)
     H2, Hp2, Hpp2, AB2 = stage_qp.blocks_from_dense(Pd, Ad, 5, 3, 2, 0)
     assert np.array_equal(H, H2) and np.array_equal(AB, AB2) and Hp2.shape == (2, 5, 0, 5) and Hpp2.shape == (2, 0, 0)
+
+
+C_EXE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "support", "stageqp_c_test")
+
+
+def test_stage_form_from_plain_c_without_gpu(built):
+    """include/mpcqp.h compiles as C99 (gcc -std=c99 -Wall in __graft_entry__.build), the host-only calls work from C, and without a GPU
+    the create call refuses loudly"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; see the gpu-marked test")
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert "pattern ok" in r.stdout and "no usable gfx950 GPU" in r.stderr
+
+
+@pytest.mark.gpu
+def test_stage_form_from_plain_c_on_gpu(built):
+    import subprocess
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "5 instances solved" in r.stdout
