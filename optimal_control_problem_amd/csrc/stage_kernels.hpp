@@ -29,10 +29,16 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
                                                          double *__restrict__ P, double *__restrict__ q, double *__restrict__ A,
                                                          double *__restrict__ l, double *__restrict__ u) {
   constexpr int nx = M::nx, nu = M::nu, f = nx + nu;
+  // cooperative functors (sm_has_coop): the f lanes of a stage sit in one wave at a multiple of f -- the parameter columns get a group of f thread
+  // slots of their own (nx of them used), every frame the next f; threads per instance f (N + 1) instead of n
+  constexpr bool COOP = sm_has_coop<M>::value && (64 % f == 0) && nx <= f;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = sd.n, N = sd.N;
-  if (gid >= (long)batch * n) return;
-  const int b = (int)(gid / n), j = (int)(gid - (long)b * n);
+  const int per = COOP ? f * (N + 1) : n;
+  if (gid >= (long)batch * per) return;
+  const int b = (int)(gid / per), jt = (int)(gid - (long)b * per);
+  if (COOP && jt < f && jt >= nx) return;       // (padding lanes of the parameter group)
+  const int j = COOP ? (jt < f ? jt : jt - f + nx) : jt;
   const double *pb = p + (long)b * nx, *xb = x + (long)b * sd.nvar;
   double *Pc = P + (long)b * sd.nnzP + sd.Pp[j], *Ac = A + (long)b * sd.nnzA + sd.Ap[j];
   double *qb = q + (long)b * n, *lb = l + (long)b * sd.m, *ub = u + (long)b * sd.m;
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(256) stage_eval_kernel(StageDev sd, int batch,
   if (k >= 1 && c < nx) Ac[a++] = 1.0;
   if (k < N - 1) {
     Dual out[nx];
-    M::template F<Dual>(sd.par, sd.dt, s, uu, out);
+    if constexpr (COOP) M::Fc(sd.par, sd.dt, s, uu, out, c); else M::template F<Dual>(sd.par, sd.dt, s, uu, out);
 #pragma unroll
     for (int r = 0; r < nx; r++) Ac[a + r] = -out[r].d;
     a += nx;
@@ -256,7 +262,8 @@ __global__ void __launch_bounds__(256) stage_merit_kernel(StageDev sd, int batch
 template <class M>
 inline hipError_t stage_launch_eval(const StageDev &sd, int batch, const double *p, const double *x, const double *lbx, const double *ubx,
                                     const double *lbg, const double *ubg, double *P, double *q, double *A, double *l, double *u, hipStream_t st) {
-  const long threads = (long)batch * sd.n;
+  constexpr int f = M::nx + M::nu;
+  const long threads = (long)batch * ((sm_has_coop<M>::value && (64 % f == 0) && M::nx <= f) ? f * (sd.N + 1) : sd.n);
   stage_eval_kernel<M><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(sd, batch, p, x, lbx, ubx, lbg, ubg, P, q, A, l, u);
   return hipGetLastError();
 }

@@ -8,6 +8,7 @@
 // host and device values agree to rounding of sin/cos.
 #pragma once
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #if defined(__HIPCC__)
@@ -50,26 +51,34 @@ SM_HD double sm_val(Dual a) { return a.v; }
 SM_HD double sm_der(double) { return 0.0; }
 SM_HD double sm_der(Dual a) { return a.d; }
 
+// a functor with a cooperative F (Fc: the lanes of a stage share the value part's expensive pieces) says so with `coop`; generated functors have none
+template <class M, class = void> struct sm_has_coop : std::false_type {};
+template <class M> struct sm_has_coop<M, std::void_t<decltype(M::coop)>> : std::bool_constant<(M::coop != 0)> {};
+
 enum { SM_DOUBLE_INTEGRATOR = 0, SM_QUADROTOR = 1, SM_CARTPOLE = 2, SM_NMODELS = 3 };
 constexpr int SM_MAXNX = 16, SM_MAXNU = 8, SM_NPAR = 8, SM_MAXNH = 16, SM_MAXNK = 8;
 
-// continuous dynamics + RK4 over dt (models.py StageOCP.F); models with a closed-form discrete map override F
-template <class M, class T>
-SM_HD void sm_rk4(const double *par, double h, const T *s, const T *u, T *out) {
-  constexpr int nx = M::nx;
+// continuous dynamics + RK4 over dt (models.py StageOCP.F); models with a closed-form discrete map override F.  `cd(state, derivative)` is the
+// continuous dynamics at fixed u (a callable, so that a model can pass a cooperative form of it: SmQuadrotor::Fc)
+template <int nx, class T, class CD>
+SM_HD void sm_rk4_with(double h, const T *s, T *out, CD &&cd) {
   T k[nx], acc[nx], st[nx];
-  M::cdyn(par, s, u, k);
+  cd(s, k);
 #pragma unroll
   for (int i = 0; i < nx; i++) { acc[i] = k[i]; st[i] = s[i] + (0.5 * h) * k[i]; }
-  M::cdyn(par, st, u, k);
+  cd(st, k);
 #pragma unroll
   for (int i = 0; i < nx; i++) { acc[i] = acc[i] + 2.0 * k[i]; st[i] = s[i] + (0.5 * h) * k[i]; }
-  M::cdyn(par, st, u, k);
+  cd(st, k);
 #pragma unroll
   for (int i = 0; i < nx; i++) { acc[i] = acc[i] + 2.0 * k[i]; st[i] = s[i] + h * k[i]; }
-  M::cdyn(par, st, u, k);
+  cd(st, k);
 #pragma unroll
   for (int i = 0; i < nx; i++) out[i] = s[i] + (h / 6.0) * (acc[i] + k[i]);
+}
+template <class M, class T>
+SM_HD void sm_rk4(const double *par, double h, const T *s, const T *u, T *out) {
+  sm_rk4_with<M::nx, T>(h, s, out, [&](const T *st, T *k) { M::cdyn(par, st, u, k); });
 }
 
 // nx = 2, nu = 1; exact zero-order-hold map (models.py DoubleIntegrator.F); no parameters
@@ -85,10 +94,14 @@ struct SmDoubleIntegrator {
 // 12-state quadrotor (models.py Quadrotor.cdyn); par = {mass, grav, arm, kappa, Jx, Jy, Jz}
 struct SmQuadrotor {
   static constexpr int nx = 12, nu = 4, nh = 0, nk = 0, has_cost = 0, has_term = 0;
+  static constexpr int coop = 1;      // has Fc: the lanes of a stage evaluate the trigonometry together (stage_kernels.hpp)
   template <class T> SM_HD static void H(const T *, const T *, T *) {}
-  template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) {
+  // t = {sin, cos} of roll, pitch, yaw
+  template <class T> SM_HD static void trig(const T *s, T *t) { t[1] = sm_cos(s[3]); t[0] = sm_sin(s[3]); t[3] = sm_cos(s[4]); t[2] = sm_sin(s[4]); t[5] = sm_cos(s[5]); t[4] = sm_sin(s[5]); }
+  template <class T> SM_HD static void cdyn(const double *par, const T *s, const T *u, T *ds) { T t[6]; trig(s, t); cdyn_t(par, s, u, t, ds); }
+  template <class T> SM_HD static void cdyn_t(const double *par, const T *s, const T *u, const T *t, T *ds) {
     const double mass = par[0], grav = par[1], arm = par[2], kappa = par[3], Jx = par[4], Jy = par[5], Jz = par[6];
-    const T cph = sm_cos(s[3]), sph = sm_sin(s[3]), cth = sm_cos(s[4]), sth = sm_sin(s[4]), cps = sm_cos(s[5]), sps = sm_sin(s[5]);
+    const T cph = t[1], sph = t[0], cth = t[3], sth = t[2], cps = t[5], sps = t[4];
     const T tth = sth / cth;
     const T thrust = u[0] + u[1] + u[2] + u[3];
     const T a = thrust / mass;
@@ -106,6 +119,27 @@ struct SmQuadrotor {
     ds[11] = (tz - (Jy - Jx) * p_ * q_) / Jz;
   }
   template <class T> SM_HD static void F(const double *par, double h, const T *s, const T *u, T *out) { sm_rk4<SmQuadrotor, T>(par, h, s, u, out); }
+#if defined(__HIPCC__)
+  // F on dual numbers for the f = 16 lanes of one stage together (stage_eval_kernel: lane r of the group carries direction r, the VALUE parts of s and
+  // u are the same in all of them -- and so are those of every RK4 stage state).  The six sines and cosines of a cdyn call are what the evaluation
+  // spends its time on (f64 sin / cos: ~70 instructions each, times 6, times 4 RK4 stages, in each of the 16 lanes): lane r < 3 evaluates angle r, the
+  // values travel by shuffle, and every lane applies its own derivative part: one sin + one cos per call instead of three each.  Same values, same
+  // operation order everywhere else: the result is bitwise F<Dual>'s.
+  __device__ static void Fc(const double *par, double h, const Dual *s, const Dual *u, Dual *out, const int r) {
+    const int base = (int)(threadIdx.x & 63) - r;
+    sm_rk4_with<nx, Dual>(h, s, out, [&](const Dual *st, Dual *k) {
+      const double a = r == 0 ? st[3].v : (r == 1 ? st[4].v : st[5].v);
+      double sv, cv; sincos(a, &sv, &cv);
+      Dual t[6];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double sq = __shfl(sv, base + q, 64), cq = __shfl(cv, base + q, 64);
+        t[2 * q] = {sq, cq * st[3 + q].d}; t[2 * q + 1] = {cq, -sq * st[3 + q].d};
+      }
+      cdyn_t(par, st, u, t, k);
+    });
+  }
+#endif
 };
 
 // cart-pole, s = [x, theta, xdot, thetadot], theta = 0 upright (models.py CartPole.cdyn); par = {mc, mp, length, grav}
