@@ -822,8 +822,11 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   if (!h->dA) { if ((rc = dalloc(h, &h->dA, (size_t)std::max<long>(wA, 1) * B))) return rc; }
   if (!h->dl) { if ((rc = dalloc(h, &h->dl, (size_t)std::max<long>(m, 1) * B))) return rc; }
   if (!h->du) { if ((rc = dalloc(h, &h->du, (size_t)std::max<long>(m, 1) * B))) return rc; }
-  // a slice's kernel ends with a tail (its slowest instance); several slices in flight fill each other's tails
-  const int ns = std::min(chunks, mpcqp_handle::NPIPE);
+  // a slice's kernel ends with a tail (its slowest instance); two slices in flight fill each other's tails.  Two compute streams, not one per slice: the
+  // runtime maps streams onto a few hardware queues (four by default), and with eight compute streams beside the copy stream the copies of a later slice
+  // queued up behind kernels of earlier ones (rocprofv3 memory-copy trace: gaps of 0.9 - 1.7 ms in the transfer; 12.3 -> 10.3 ms per step on the north-star
+  // batch, against a bound of ~10 ms = transfer of one slice + the launch).  MPCQP_PIPE_STREAMS overrides (1 .. 8).
+  const int ns = std::min(chunks, getenv("MPCQP_PIPE_STREAMS") ? std::max(1, std::min(atoi(getenv("MPCQP_PIPE_STREAMS")), (int)mpcqp_handle::NPIPE)) : 2);
   for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
   DevIO io = h->io;
   io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;

@@ -62,7 +62,7 @@ for a, b in (("bench_gpus2.json", "r03_bench_gpus2_share_gpu_rehearsal.json"), (
             json.dump(json.loads(txt) if txt.startswith("[\n") else json.loads(cand[-1]), open(os.path.join(DST, b), "w"), indent=1)
         except ValueError:
             print("skipped", a, file=sys.stderr)
-for a, b in (("stageqp_bench.txt", "r03_stageqp_bench.txt"), ("chain_stage_probe.txt", "r03_chain_stage_probe.txt")):
+for a, b in (("stageqp_bench.txt", "r03_stageqp_bench.txt"), ("chain_stage_probe.txt", "r03_chain_stage_probe.txt"), ("host_pipeline.txt", "r03_host_pipeline.txt")):
     p = os.path.join(SRC, a)
     if os.path.exists(p) and os.path.getsize(p) > 2:
         open(os.path.join(DST, b), "w").writelines(l for l in open(p) if "amdgpu.ids" not in l)

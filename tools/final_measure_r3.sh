@@ -28,5 +28,6 @@ python bench.py --gpus 2 --share-gpu --no-extras --no-cpu-baseline --batch 4096 
 python tools/sqp_bench.py quadrotor 20 8192 10 0.5 1 16 > $out/sqp_device_loop.json 2> $out/sqp_device_loop.err
 python tools/config_sweep.py > $out/config_sweep.json 2> $out/config_sweep.err
 python tools/stageqp_bench.py > $out/stageqp_bench.txt 2> $out/stageqp_bench.err
+python tools/host_pipeline.py 4 6 8 12 > $out/host_pipeline.txt 2> $out/host_pipeline.err
 tools/probes/bin/chain_stage_probe > $out/chain_stage_probe.txt 2>&1
 echo done
