@@ -16,11 +16,14 @@ for cfg in "q20 --workload quadrotor" "q50 --workload quadrotor --horizon 50 --b
   done
   echo "== $tag"; cat $out/pmc_$tag.txt; grep -h mpcqp_res_kernel $out/kstats_$tag/*/*kernel_stats.csv | head -2
 done
-for ctr in TCC_HIT_sum TCC_MISS_sum; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_q20_$ctr -- python3 bench.py --steps 3 --warmup 2 --no-extras --no-cpu-baseline > $out/pmc_q20_$ctr.log 2>&1 || exit 1
-  python tools/pmc_summary.py $out/pmc_q20_$ctr $ctr >> $out/pmc_q20.txt
+for cfg in "q20 --workload quadrotor" "q50 --workload quadrotor --horizon 50 --batch 8192" "cp100 --workload cartpole"; do
+  set -- $cfg; tag=$1; shift
+  for ctr in TCC_HIT_sum TCC_MISS_sum; do
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${tag}_$ctr -- python3 bench.py "$@" --steps 3 --warmup 2 --no-extras --no-cpu-baseline > $out/pmc_${tag}_$ctr.log 2>&1 || exit 1
+    python tools/pmc_summary.py $out/pmc_${tag}_$ctr $ctr >> $out/pmc_$tag.txt
+  done
+  cat $out/pmc_$tag.txt
 done
-cat $out/pmc_q20.txt
 MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py quadrotor 8192 > $out/timing_breakdown_q20.txt 2>&1
 MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py quadrotor 8192 - 50 > $out/timing_breakdown_q50.txt 2>&1
 MPCQP_LIB=optimal_control_problem_amd/libmpcqp_timing.so python tools/timing_breakdown.py cartpole 16384 - 100 > $out/timing_breakdown_cp100.txt 2>&1
