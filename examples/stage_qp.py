@@ -27,6 +27,8 @@ l[:, n:] = 0.0; u[:, n:] = 0.0                                              # s_
 
 qp = StageQP(N, nx, nu, B)                                                  # np_ = 0: no parameter block
 qp.update_blocks(H, None, None, AB, q, l, u)
+qp.solve(); qp.sync()                                                     # (first launch: code load)
+qp.update_blocks(H, None, None, AB, q, l, u)
 qp.solve()
 res = qp.get()
 x = res["x"].reshape(B, N, f)
