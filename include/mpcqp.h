@@ -180,6 +180,10 @@ const char *mpcqp_strerror(int code);            /* replaces the std::cerr messa
  * std::chrono, SQPOptimizationSolver.cpp:153-160).  Duration of the last solve kernel from HIP events
  * recorded around the launch on its stream (waits for the kernel). */
 int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms);
+/* The same split by the reference's two calls, where the handle runs them as two kernels (the on-chip mode: variant 200 + NW):
+ * setup_ms = the set-up kernel (CuCaQP::initSolver, CuCaQP.cpp:183-197), solve_ms = the iteration kernel (CuCaQP::solve,
+ * CuCaQP.cpp:199-211).  Handles that do both in one kernel report setup_ms = 0 and the whole kernel in solve_ms. */
+int mpcqp_last_phase_ms(mpcqp_handle *h, float *setup_ms, float *solve_ms);
 /* info[0..15]: n, m, batch, npad, mpad, n_blocks(n/16), L_blocks, lds_bytes_per_qp, workspace_bytes_per_qp,
  * ordering(0 natural,1 hubs-last,2 twisted), nnzP_triu, nnzA, T_blocks, factor_ops (on-chip kernels: the number of dense 16 x 16 tiles of A the
  * iteration's two sweeps run on, 0 = ELL only), ell_slots_total,

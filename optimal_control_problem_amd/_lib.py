@@ -15,7 +15,7 @@ STATUS = {1: "solved", 2: "solved_inaccurate", 3: "primal_infeasible", 4: "prima
           5: "dual_infeasible", 6: "dual_infeasible_inaccurate", 7: "max_iter_reached", 9: "non_cvx", 11: "unsolved"}
 
 EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_create_tuned", "mpcqp_create_reduced", "mpcqp_update", "mpcqp_warm_start", "mpcqp_keep_workspace", "mpcqp_update_vectors", "mpcqp_set_rho", "mpcqp_set_dispatch_hint", "mpcqp_solve", "mpcqp_solve_host",
-           "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms",
+           "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms", "mpcqp_last_phase_ms",
            "mpcqp_plan_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
            "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_set_path_bounds", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
            "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step",
@@ -41,9 +41,9 @@ class MpcqpError(RuntimeError):
 def build(force=False):
     """Compile libmpcqp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in ("mpcqp.hip", "kernels_common.hpp", "kernel_stream.hpp", "kernel_onchip.hpp", "kernel_resident.hpp", "kernels_util.hpp", "reduced.hpp", "plan.hpp", "stage_eval.hip", "stageqp.hip", "stage_models.hpp", "stage_kernels.hpp", "common.hpp")] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
+    deps = [os.path.join(src, f) for f in sorted(os.listdir(src)) if f.endswith((".hip", ".hpp")) or f == "Makefile"] + [os.path.join(_HERE, "..", "include", "mpcqp.h")]
     if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps):
-        subprocess.check_call(["make", "-C", src, "-B", "../libmpcqp.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src, "-j", str(min(8, os.cpu_count() or 1))] + (["-B"] if force else []) + ["../libmpcqp.so"], stdout=subprocess.DEVNULL)
     return SO_PATH
 
 
@@ -85,6 +85,7 @@ def lib():
         L.mpcqp_strerror.argtypes = [C.c_int]
         L.mpcqp_strerror.restype = C.c_char_p
         L.mpcqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.mpcqp_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mpcqp_plan_info.argtypes = [vp, vp]
         L.mpcqp_debug_scaling.argtypes = [vp, C.c_int, dp, dp, dp]
         L.mpcqp_debug_blockops.argtypes = [dp, dp, dp, dp, dp, dp, vp]

@@ -1,0 +1,16 @@
+// k_oc_admm_rf.hip -- instances of mpcqp_oc_admm_kernel<..., RF = 1> (kernel_oc_split.hpp): CuCaQP::solve's half of the on-chip mode;
+// an adaptive-rho step re-factorises in place (the last launch of a solve, for instances with more rho updates than resume rounds)
+#include "kernels_all.hpp"
+MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm_rf(int nw, int ng, int nh) {
+  constexpr int RF = 1;
+  if (nw == 4 && ng == OC_NG) {
+    if (nh == OC_NH) return (const void *)mpcqp_oc_admm_kernel<4, OC_NG, OC_NH, RF>;
+    if (nh == 0) return (const void *)mpcqp_oc_admm_kernel<4, OC_NG, 0, RF>;
+    return nullptr;
+  }
+  if (nw == 8) {
+    if (ng == OC8_INST[0].ng && nh == OC8_INST[0].nh) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[0].ng, OC8_INST[0].nh, RF>;
+    if (ng == OC8_INST[1].ng && nh == OC8_INST[1].nh) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[1].ng, OC8_INST[1].nh, RF>;
+  }
+  return nullptr;
+}

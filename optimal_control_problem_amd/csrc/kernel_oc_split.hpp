@@ -1,0 +1,443 @@
+// kernel_oc_split.hpp -- the on-chip mode as TWO kernels, one per call of the reference's seam:
+//   mpcqp_oc_setup_kernel  = CuCaQP::initSolver (reference src/sqp_solver/CuCaQP.cpp:183-197 -> osqp_setup): load the caller's CSC values, modified
+//                            Ruiz equilibration, scaled ELL copies, rho vector, assembly of M, block LDL' on the matrix cores (oc_ldl); the
+//                            factor lands in the slab exactly where oc_load_factor reads it
+//   mpcqp_oc_admm_kernel   = CuCaQP::solve (:199-211 -> osqp_solve): factor brought on chip (LDS + registers), ADMM iterations, termination /
+//                            infeasibility tests, adaptive rho (re-factorisation in place, a rare path), un-scaled outputs
+// Same stream, same dispatch order, one launch each per mpcqp_solve.  Why two: in the single kernel (kernel_resident.hpp mpcqp_res_kernel<..., OCG,
+// OCH>) the set-up and the iteration shared one register allocation -- 654 - 1,139 spilled VGPRs, 464 - 980 B of scratch per lane in the three
+// BASELINE instances -- and nothing could be done for one phase without moving the other's schedule.  Here each phase has its own allocation, and the
+// set-up, in which no factor block is resident yet, may use every wave and register of the workgroup.
+// What crosses from one kernel to the other, per QP, through the slab: the scaled ELL values, l, u, D, E (as before), the scaled q (the slab's Lb
+// region, which the resident kernels never used), c (DevIO.cscale), rho (DevIO.info[3]) and the set-up's verdict (DevIO.status: UNSOLVED = go on,
+// NON_CVX = M is not positive definite).  The arithmetic, and therefore every result bit, is that of the single kernel.
+//
+// Adaptive rho.  A new rho means a new factor: rare (every 100th iteration at most, and only when the residual ratio moved by more than a factor
+// of five), but inlined into the iteration kernel it costs that kernel its register allocation (600 - 900 of its 700 - 1,100 spilled VGPRs).  So the
+// iteration kernel <RF = 0> LEAVES when rho changes: it parks x, z, y in the slab, the iteration number in DevIO.iters, the new rho in DevIO.info[3]
+// and marks the instance OC_PENDING.  mpcqp_solve queues, unconditionally and on the same stream: the set-up kernel in `resume` mode (only the
+// re-factorisation, only for marked instances -- every other workgroup returns at once), the iteration kernel in resume mode, and, so that any
+// number of rho updates is served, a last pair whose iteration kernel <RF = 1> re-factorises in place.  A launch of workgroups that return at
+// once costs ~10 us; no instance of the MPC workloads ever reaches the last pair.
+// Part of the kernel translation units (included through kernels_all.hpp, in order; not a stand-alone header).
+#pragma once
+
+constexpr int OC_PENDING = 100, OC_PENDING_NONCVX = 101;      // DevIO.status between the launches of one mpcqp_solve (never seen by the caller)
+// LDS carve-up shared by both kernels (the same as the single kernel's on-chip mode, so that one footprint -- plan.hpp lds_bytes_oc -- serves both)
+template <int NW>
+struct OcLds {
+  double *X, *Q, *R, *Z, *Y, *W, *RB, *RED;
+  int *octab, *co;
+};
+template <int NW>
+__device__ __forceinline__ OcLds<NW> oc_lds(double *lds, const DevPlan &pl, const DevRes &rs, const DevOc &oc) {
+  OcLds<NW> L;
+  L.X = lds + rs.stage; L.Q = L.X + pl.npad; L.R = L.Q + pl.npad;
+  double *rend = L.R + pl.npad + rs.rext;
+  L.Z = rend; L.Y = L.Z + pl.mpad; L.W = L.Y + pl.mpad;
+  L.RB = L.W + pl.mpad; L.RED = L.RB + 16 * NW + 16;
+  L.octab = reinterpret_cast<int *>(L.RED + 16 * NW) + 8;
+  L.co = L.octab + ((oc.o_pos + 1) & ~1);
+  return L;
+}
+// Which wave plays which part is free.  The two workgroups of a CU put their chain waves (0, 1: the only ones busy in the chain phases of the solve
+// and of oc_ldl, bound by dependent MFMAs) on different SIMDs: the wave on SIMD s of the workgroup in LDS slot k takes part (s + 2 k) mod 4.
+// HW_ID[5:4] = SIMD, LDS_ALLOC[7:0] = LDS base (0: the CU's first slot).  Only when the four waves do sit on four SIMDs.
+__device__ __forceinline__ int oc_wave_role4(double *lds, int wid, const int lane, const int no_remap) {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), la = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+  const int simd = (hw >> 4) & 3, slot = (la & 0xff) != 0;
+  int *xs = reinterpret_cast<int *>(lds);
+  if (lane == 0) xs[wid] = simd;
+  bsync<4>();
+  const int seen = (1 << xs[0]) | (1 << xs[1]) | (1 << xs[2]) | (1 << xs[3]);
+  bsync<4>();
+  if (seen == 15 && !no_remap) wid = __builtin_amdgcn_readfirstlane((simd + 2 * slot) & 3);
+  return wid;
+}
+// chain tables and chunk offsets into LDS (every chunk of every sweep starts by reading two offsets: a slab round trip less each)
+template <int NW>
+__device__ __forceinline__ void oc_tables_to_lds(const DevPlan &pl, const DevOc &oc, RCtx &cx, const OcLds<NW> &L, const int tid) {
+  constexpr int NT = NW * WAVE;
+  for (int k = tid; k < oc.o_pos; k += NT) L.octab[k] = oc.tab[k];
+  int *co = L.co;
+  for (int k = tid; k <= pl.A.nchunks; k += NT) co[k] = pl.A.chunk_off[k];
+  for (int k = tid; k <= pl.At.nchunks; k += NT) co[pl.A.nchunks + 1 + k] = pl.At.chunk_off[k];
+  for (int k = tid; k <= pl.P.nchunks; k += NT) co[pl.A.nchunks + pl.At.nchunks + 2 + k] = pl.P.chunk_off[k];
+  cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
+}
+
+// The re-factorisation of an adaptive-rho step, OUT OF LINE.  Inlined into the iteration kernel (as the single kernel has it) its register pressure
+// -- twelve operand tiles of the assembly, nine carried blocks of oc_ldl -- was behind 600 - 900 of that kernel's 700 - 1,100 spilled VGPRs although
+// it runs once in a hundred iterations, if at all.  As a function of its own it has its own allocation; the caller's resident blocks are dead across
+// the call (the factor is brought on chip again right after it).  It takes nothing that points into the kernel's argument segment (a kernel argument
+// whose address escapes into a call is copied to scratch, and the iteration would read it from there): the arguments it needs are read from a
+// copy in global memory that mpcqp_create uploads once, and the LDS carve-up is rebuilt from the LDS base.
+struct OcCold { DevPlan pl; DevRes rs; mpcqp_settings st; DevOc oc; };
+typedef __attribute__((address_space(3))) double lds_double;
+template <int NW, bool HUB>
+__device__ __attribute__((noinline)) bool oc_refactor_cold(const OcCold *__restrict__ g, lds_double *ldsp, double *ws, const int wid, const double rho) {
+  double *lds = (double *)ldsp;
+  const OcLds<NW> L = oc_lds<NW>(lds, g->pl, g->rs, g->oc);
+  RCtx cx;
+  cx.pl = &g->pl; cx.rs = &g->rs; cx.st = &g->st; cx.wid = wid; cx.lane = threadIdx.x & 63;
+  cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
+  cx.ws = ws; cx.BL = ws + g->pl.o_Lf; cx.TMP = lds;
+  cx.X = L.X; cx.Q = L.Q; cx.R = L.R; cx.Z = L.Z; cx.Y = L.Y; cx.W = L.W; cx.RB = L.RB; cx.RED = L.RED;
+  cx.coA = L.co; cx.coAt = L.co + g->pl.A.nchunks + 1; cx.coP = L.co + g->pl.A.nchunks + g->pl.At.nchunks + 2;
+  cx.rho = rho; cx.c = 1.0; cx.cinv = 1.0; cx.unscale = 0;      // (the factorisation reads rho only)
+  return factorize_res<NW, (HUB ? 2 : 1)>(cx, &g->oc, L.octab, lds);
+}
+
+#ifdef MPCQP_TIMING
+// (the two kernels share a QP's row of 16 slots: each adds its own)
+#define TS_STORE_ADD(ptr, k0, k1) do { if (tid == 0 && (ptr)) { for (int k_ = (k0); k_ < (k1); k_++) (ptr)[16L * b + k_] += (long long)ts_acc[k_]; \
+    if (b == 0) { (ptr)[16L * gridDim.x + 126] += (long long)(__builtin_amdgcn_s_memtime() - ts_first); (ptr)[16L * gridDim.x + 127] += (long long)(__builtin_amdgcn_s_memrealtime() - ts_rt0); } } } while (0)
+#else
+#define TS_STORE_ADD(ptr, k0, k1)
+#endif
+
+// =========================================================================================================
+// Set-up: what osqp_setup does per QP.  REUSE = the kept-workspace entry (mpcqp_update_vectors; OSQP's osqp_update_data_vec): P, A, D, E, c, rho and
+// the factor stay, q, l, u are replaced and scaled with the kept D, E, c; the factor is rebuilt only when a row changed its class (rho_i depends on it).
+// =========================================================================================================
+template <int NW, bool REUSE, bool HUB>
+__global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = NW * WAVE;
+  const int lane = threadIdx.x & 63;
+  const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
+  int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
+  const int tid = wid * WAVE + lane;
+  const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
+  RCtx cx;
+  cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
+  cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
+  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
+  cx.BL = ws + pl.o_Lf; cx.TMP = lds;
+  cx.X = L.X; cx.Q = L.Q; cx.R = L.R; cx.Z = L.Z; cx.Y = L.Y; cx.W = L.W; cx.RB = L.RB; cx.RED = L.RED;
+  double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt, *valP = ws + pl.o_ellP;
+  double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E, *Qs = ws + pl.o_Lb;
+  const double *inP = io.P + (long)b * io.sP, *inA = io.A + (long)b * io.sA, *inq = io.q + (long)b * io.sq;
+  const double *inl = io.l + (long)b * io.sl, *inu = io.u + (long)b * io.su;
+  const int n = pl.n, m = pl.m, npad = pl.npad, mpad = pl.mpad;
+  cx.unscale = st.scaling && !st.scaled_termination;
+  TS_DECL;
+#ifdef MPCQP_TIMING_RUIZ
+  unsigned long long rzacc[5] = {0, 0, 0, 0, 0};
+#endif
+  if (oc.resume && io.status[b] != OC_PENDING) return;      // (resume mode: only the instances that left the iteration kernel for a new factor)
+  oc_tables_to_lds<NW>(pl, oc, cx, L, tid);
+  if (oc.resume) {
+    bsync<NW>();
+    cx.rho = uni(io.info[4L * b + 3]);
+    cx.c = 1.0; cx.cinv = 1.0;
+    const bool okr = factorize_res<NW, (HUB ? 2 : 1), false>(cx, &oc, L.octab, lds);
+    if (tid == 0) io.status[b] = okr ? OC_PENDING : OC_PENDING_NONCVX;
+    return;
+  }
+  double c = 1.0;
+  int refactor = 1, prev_status = MPCQP_UNSOLVED;
+  const bool reuse = REUSE && io.reuse;
+  if (reuse) {
+    prev_status = io.status[b];
+    c = io.cscale[b];
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = Dg[t]; }
+    bsync<NW>();
+    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
+    bsync<NW>();
+    for (int t = tid; t < npad; t += NT) cx.Q[t] *= c * cx.R[t];
+    double chg[1] = {0.0};
+    for (int i = tid; i < mpad; i += NT) {
+      const double ei = Eg[i];
+      const double nl = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0, nu = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+      if (i < m) {
+        const double ol = lb[i], ou = ub[i];
+        const int oc_ = (ol < -Q_INFTY * Q_MIN_SCALING && ou > Q_INFTY * Q_MIN_SCALING) ? 0 : (ou - ol < Q_RHO_TOL ? 2 : 1);
+        const int nc = (nl < -Q_INFTY * Q_MIN_SCALING && nu > Q_INFTY * Q_MIN_SCALING) ? 0 : (nu - nl < Q_RHO_TOL ? 2 : 1);
+        if (oc_ != nc) chg[0] = 1.0;
+      }
+      lb[i] = nl; ub[i] = nu;
+    }
+    block_combine<NW, 1, 0>(chg, cx.RED, wid, lane);
+    refactor = chg[0] != 0.0;
+    c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
+    bsync<NW>();
+  } else {
+    // ---- load: caller's CSC values -> ELL arrays.  The block slots of LDS are idle until the factor comes on chip (in the other kernel), so the
+    // ELL values of A (and P behind them) live there for the whole scaling phase when they fit (oc.a_lds / oc.p_lds, decided by the host) and
+    // are written to the slab once, already scaled; A' is gathered from the caller's array when it is scaled.
+    const bool a_lds = oc.a_lds, p_lds = oc.p_lds;
+    double *sA = a_lds ? lds : valA, *sP = p_lds ? lds + pl.A.entries : valP;
+    for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
+    for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }
+    for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
+    bsync<NW>();
+    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
+    bsync<NW>();
+    TS(0);
+    // ---- modified Ruiz equilibration: D in R, E in W; X = the column-norm accumulators of the sweep over A (one sweep by rows gives the row norm,
+    // lane-local, and the column norms, LDS atomic max on the bit pattern); nP = max_k |P_tk| d_k is needed twice per pass -- before and after D
+    // is updated -- and swept once (the second value is the next pass's first; it lives in y, idle here; in the slab when m < n)
+    c = 1.0;
+    double *nPv = mpad >= npad ? cx.Y : ws + pl.o_dx;
+    if (st.scaling > 0) ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) nPv[t] = x; });
+    for (int it = 0; it < st.scaling; it++) {
+      RZ_T0;
+      for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+        const int i = ch * WAVE + lane;
+        const double ei = i < mpad ? cx.W[i] : 0.0;
+        const double v = ell_chunk_rc(sA, pl.A.idx, cx.R, ei, cx.X, cx.coA[ch], cx.coA[ch + 1], lane);
+        if (i < mpad) cx.W[i] = ei * (1.0 / sqrt(limit_scaling(ei * v)));       // (e_i is read by its own lane only: updated in place)
+      }
+      RZ_T(4);
+      bsync<NW>();
+      RZ_T(5);
+      for (int t = tid; t < npad; t += NT) {       // (the thread that wrote nPv[t])
+        const double dj = cx.R[t];
+        cx.R[t] = dj * (1.0 / sqrt(limit_scaling(fmax(c * dj * nPv[t], dj * cx.X[t]))));
+        cx.X[t] = 0.0;
+      }
+      bsync<NW>();
+      RZ_T(6);
+      double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
+      ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+      RZ_T(7);
+      block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
+      const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
+      c *= ct;
+      bsync<NW>();
+      RZ_T(8);
+    }
+    c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
+    TS(1);
+    // scale and write out: A <- E A D, A' likewise (gathered from the caller's array), P <- c D P D (coalesced stores of whole 512 B slots; up to 8 slots in flight)
+    for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+      const int i = ch * WAVE + lane; const double ei = i < mpad ? cx.W[i] : 0.0;
+      ell_map_chunk<false>(sA, pl.A.idx, nullptr, pl.A.idx, valA, cx.coA[ch], cx.coA[ch + 1], lane, [&](double v, int j) { return v * (ei * cx.R[j]); });
+    }
+    for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+      const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+      ell_map_chunk<true>(valAt, pl.At.src, inA, pl.At.idx, valAt, cx.coAt[ch], cx.coAt[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
+      ell_map_chunk<false>(sP, pl.P.idx, nullptr, pl.P.idx, valP, cx.coP[ch], cx.coP[ch + 1], lane, [&](double v, int k) { return v * (c * dj * cx.R[k]); });
+    }
+    bsync<NW>();
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
+    for (int i = tid; i < mpad; i += NT) {
+      const double ei = cx.W[i];
+      Eg[i] = ei;
+      lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
+      ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
+    }
+  }
+  for (int t = tid; t < npad; t += NT) Qs[t] = cx.Q[t];         // the scaled q crosses to the iteration kernel through the slab
+  bsync<NW>();
+  // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
+  cx.rho = uni(reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX));
+  TS(2);
+  bool ok = !(reuse && prev_status == MPCQP_NON_CVX);
+  if (ok && refactor) ok = factorize_res<NW, (HUB ? 2 : 1), false>(cx, &oc, L.octab, lds);
+  if (tid == 0) {
+    io.status[b] = ok ? MPCQP_UNSOLVED : MPCQP_NON_CVX; io.iters[b] = 0;
+    io.info[4L * b + 3] = cx.rho;
+    io.cscale[b] = c;
+  }
+  TS(3);
+#ifdef MPCQP_TIMING
+  ts_acc[12] = cx.fts[0]; ts_acc[13] = cx.fts[1]; ts_acc[14] = cx.fts[2]; ts_acc[15] = cx.fts[3];
+#ifdef MPCQP_TIMING_RUIZ
+  ts_acc[9] = rzacc[0]; ts_acc[10] = rzacc[1]; ts_acc[11] = rzacc[2]; ts_acc[12] = rzacc[3]; ts_acc[13] = rzacc[4];
+#endif
+#endif
+  TS_STORE(io.dbg);
+}
+
+// =========================================================================================================
+// Iteration: what osqp_solve does per QP, on the factor the set-up kernel left in the slab.
+// =========================================================================================================
+// RF = 1: an adaptive-rho step re-factorises in place (the last launch of a solve); RF = 0: the instance leaves for the set-up kernel's resume mode
+template <int NW, int OCG, int OCH, int RF>
+__global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = NW * WAVE;
+  constexpr int OCU = NW == 4 ? 16 : 8;      // ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
+  constexpr bool HUB = OCH > 0;
+  const int lane = threadIdx.x & 63;
+  const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
+  int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
+  const int tid = wid * WAVE + lane;
+  const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
+  RCtx cx;
+  cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
+  cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
+  double *ws = io.ws + (long)b * pl.ws_stride; cx.ws = ws;
+  cx.BL = ws + pl.o_Lf; cx.TMP = lds;
+  cx.X = L.X; cx.Q = L.Q; cx.R = L.R; cx.Z = L.Z; cx.Y = L.Y; cx.W = L.W; cx.RB = L.RB; cx.RED = L.RED;
+  int *octab = L.octab;
+  double *ocBL = lds;
+  d4 ocG[OCG], ocHF[OCH > 0 ? OCH : 1], ocHT[OCH > 0 ? OCH : 1];
+  OcLane ocl; OcWave<OCG> ocw;
+  double *valA = ws + pl.o_ellA, *valAt = ws + pl.o_ellAt;
+  double *lb = ws + pl.o_l, *ub = ws + pl.o_u, *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
+  double *Qs = ws + pl.o_Lb, *Xs = Qs + pl.npad, *Zs = ws + pl.o_Zg, *Ys = ws + pl.o_Yg;     // the scaled q; x, z, y of an instance that left for a new factor
+  const int n = pl.n, m = pl.m, npad = pl.npad, mpad = pl.mpad;
+  cx.unscale = st.scaling && !st.scaled_termination;
+  int status = io.status[b], iter0 = 0;
+  const bool resume = oc.resume != 0;
+  if (resume && status != OC_PENDING && status != OC_PENDING_NONCVX) return;      // (not waiting for this launch)
+  TS_DECL;
+  oc_tables_to_lds<NW>(pl, oc, cx, L, tid);
+  ocl = oc_lane(lane);
+  const double c = uni(io.cscale[b]); cx.c = c; cx.cinv = uni(1.0 / c);
+  if (resume) {
+    iter0 = io.iters[b];
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = Qs[t]; cx.X[t] = Xs[t]; }
+    for (int i = tid; i < mpad; i += NT) { cx.Z[i] = Zs[i]; cx.Y[i] = Ys[i]; }
+  } else {
+    for (int t = tid; t < npad; t += NT) { cx.Q[t] = Qs[t]; cx.X[t] = 0.0; }
+    for (int i = tid; i < mpad; i += NT) { cx.Z[i] = 0.0; cx.Y[i] = 0.0; }
+  }
+  bsync<NW>();
+  if (!resume && st.warm_start && io.x0 && io.y0) {
+    for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; cx.X[t] = io.x0[(long)b * n + j] * (1.0 / Dg[t]); }
+    for (int i = tid; i < m; i += NT) cx.Y[i] = io.y0[(long)b * m + i] * (1.0 / Eg[i]) * c;
+    bsync<NW>();
+    ell_rows_w<NW>(pl.A, cx.coA, valA, cx.X, wid, lane, [&](int i, double ax) { if (i < m) cx.Z[i] = ax; });
+    bsync<NW>();
+  }
+  cx.rho = uni(io.info[4L * b + 3]);
+  int iter_done = iter0;
+  Info in; memset(&in, 0, sizeof(in));
+  if (resume) { in.obj = io.info[4L * b]; in.prim_res = io.info[4L * b + 1]; in.dual_res = io.info[4L * b + 2]; }      // (what a failed re-factorisation reports: the last check's)
+  const bool ok = status != MPCQP_NON_CVX && status != OC_PENDING_NONCVX;
+  status = ok ? MPCQP_UNSOLVED : MPCQP_NON_CVX;
+  if (ok) {
+    // w = rho z - y (what a factorisation leaves behind in the single kernel: the same product, bit for bit)
+    for (int i = tid; i < mpad; i += NT) cx.W[i] = i < m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
+    bsync<NW>();
+    ocw = oc_wave<NW, OCG, OCH>(oc, oc.tab, wid, npad);
+    oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
+  }
+  TS(3);
+
+  int interval = st.adaptive_rho_interval;
+  if (st.adaptive_rho && interval == 0) interval = st.check_termination ? 4 * st.check_termination : 100;
+  const double alpha = st.alpha, sigma = st.sigma;
+  double *dxg = ws + pl.o_dx, *dyg = ws + pl.o_dy;
+  int can_check = 0;
+  auto late_rows = [&](const int) {};
+  // what waves 2, 3 do while the chains run backwards: pull the values of A, l, u -- streamed right after the solve -- and of A' -- at the start of
+  // the next iteration -- into L2 (every iteration re-reads them, and 512 resident QPs x 90 KB do not stay in L2 by themselves)
+  auto idle_touch = [&](const int w) {
+    if (io.no_touch) return;
+    if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
+    else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
+  };
+  if (ok) {
+    int iter;
+    for (iter = iter0 + 1; iter <= st.max_iter; iter++) {
+      for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
+        const int t = ch * WAVE + lane;
+        const double v = ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, cx.coAt[ch], cx.coAt[ch + 1], lane);
+        if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
+      }
+      for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
+      bsync<NW>();
+      TS(4);
+#ifdef MPCQP_TIMING
+      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);
+#else
+      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch);
+      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch);
+#endif
+      TS(5);
+      can_check = st.check_termination && (iter % st.check_termination == 0);
+      const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
+      const int save = can_check || do_rho;
+      {
+        // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.  l, u are fetched before the row sum is
+        // accumulated; rho_i and 1 / rho_i are selected from the three values the rho rule can produce (no per-row division).
+        const double rho_eq = uni(Q_RHO_EQ * cx.rho), ri_min = 1.0 / Q_RHO_MIN, ri_eq = uni(1.0 / rho_eq), ri_in = uni(1.0 / cx.rho);
+        for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+          const int i = ch * WAVE + lane;
+          const double lo = lb[i], up = ub[i];
+          const double zt = ell_chunk<false, OCU>(valA, pl.A.idx, cx.R, cx.coA[ch], cx.coA[ch + 1], lane);
+          if (i < m) {
+            const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
+            const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
+            const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
+            const double zn = fmin(fmax(zr + rinv * yo, lo), up);
+            const double dy = rh * (zr - zn), yn = yo + dy;
+            cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
+            if (save) dyg[i] = dy;
+          }
+        }
+      }
+      bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
+      if (__builtin_expect(save, 0)) {     // (its own loop: the address of dx stays out of the iteration's live set)
+        for (int t = tid; t < npad; t += NT) { const double xo = cx.X[t]; dxg[t] = (alpha * cx.R[t] + (1.0 - alpha) * xo) - xo; }
+      }
+      for (int t = tid; t < npad; t += NT) cx.X[t] = alpha * cx.R[t] + (1.0 - alpha) * cx.X[t];
+      bsync<NW>();
+      TS(6);
+      iter_done = iter;
+      if (__builtin_expect(can_check, 0)) {     // (rare paths are marked cold: their register pressure must not cost the hot loop its registers)
+        update_info_res<NW>(cx, in);
+        status = check_termination_res<NW>(cx, in, 0);
+        TS(7);
+        if (status != MPCQP_UNSOLVED) break;
+      }
+      if (__builtin_expect(do_rho, 0)) {
+        if (!can_check) update_info_res<NW>(cx, in);
+        const double pr = in.prs / (fmax(in.nzs, in.naxs) + Q_DIV_TOL);
+        const double dr = in.drs / (fmax(in.nqs, fmax(in.natys, in.npxs)) + Q_DIV_TOL);
+        double rn = cx.rho * sqrt(pr / (dr + Q_DIV_TOL));
+        rn = fmin(fmax(rn, Q_RHO_MIN), Q_RHO_MAX);
+        if (rn > cx.rho * st.adaptive_rho_tolerance || rn < cx.rho / st.adaptive_rho_tolerance) {
+          cx.rho = uni(rn);
+          if constexpr (RF == 0) {
+            // leave for a new factor: the set-up kernel's resume mode builds it, the next launch of this kernel goes on from here
+            for (int t = tid; t < npad; t += NT) Xs[t] = cx.X[t];
+            for (int i = tid; i < mpad; i += NT) { Zs[i] = cx.Z[i]; Ys[i] = cx.Y[i]; }
+            if (tid == 0) {
+              io.status[b] = OC_PENDING; io.iters[b] = iter;
+              io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
+            }
+            return;
+          } else {
+#ifdef MPCQP_COLD_CALL
+            if (!oc_refactor_cold<NW, HUB>(reinterpret_cast<const OcCold *>(oc.cold), (lds_double *)lds, ws, wid, cx.rho)) { status = MPCQP_NON_CVX; break; }
+#else
+            if (!factorize_res<NW, (HUB ? 2 : 1)>(cx, &oc, octab, ocBL)) { status = MPCQP_NON_CVX; break; }
+#endif
+            oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
+          }
+        }
+      }
+    }
+    if (iter > st.max_iter) iter_done = st.max_iter;
+    if (status == MPCQP_UNSOLVED) {
+      if (!can_check) { update_info_res<NW>(cx, in); status = check_termination_res<NW>(cx, in, 0); }
+      if (status == MPCQP_UNSOLVED) { status = check_termination_res<NW>(cx, in, 1); if (status == MPCQP_UNSOLVED) status = MPCQP_MAX_ITER_REACHED; }
+    }
+  }
+  const bool bad = status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
+                   status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX;
+  for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; io.x[(long)b * n + j] = bad ? NAN : Dg[t] * cx.X[t]; }
+  for (int i = tid; i < m; i += NT) {
+    io.y[(long)b * m + i] = bad ? NAN : cx.cinv * Eg[i] * cx.Y[i];
+    io.z[(long)b * m + i] = bad ? NAN : (1.0 / Eg[i]) * cx.Z[i];
+  }
+  if (tid == 0) {
+    io.status[b] = status; io.iters[b] = iter_done;
+    io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
+  }
+  TS(8);
+#ifdef MPCQP_TIMING
+  ts_acc[12] += cx.fts[0]; ts_acc[13] += cx.fts[1]; ts_acc[14] += cx.fts[2]; ts_acc[15] += cx.fts[3];
+#endif
+  TS_STORE_ADD(io.dbg, 0, 16);
+}

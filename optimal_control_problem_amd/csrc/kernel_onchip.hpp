@@ -35,7 +35,9 @@ struct DevOc {
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
   const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
-  DevTile tl;           // (last: the instances without tiles keep their argument layout)
+  DevTile tl;           // (the instances without tiles keep their argument layout)
+  const void *cold;     // two-kernel form: the kernel arguments once more in global memory (kernel_oc_split.hpp OcCold), for the out-of-line re-factorisation
+  int resume;           // two-kernel form: this launch continues instances that left the iteration kernel for a re-factorisation (kernel_oc_split.hpp)
 };
 
 // LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart, the four

@@ -15,7 +15,12 @@
 // (phase boundaries stay scheduling boundaries in the product build: the timing build, whose time stamps make them so, was 6.5 % FASTER on the
 // 12-state quadrotor -- without them the compiler moves loads of the next phase up into a phase whose registers are all spoken for)
 #define TS_DECL
+#ifdef MPCQP_ASM_MARKS
+// (tools/isa_scratch_map.py: the phase boundaries as comments in the device assembly, to tell which phase a scratch access belongs to)
+#define TS(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; TS " #k ::: "memory"); } while (0)
+#else
 #define TS(k) __builtin_amdgcn_sched_barrier(0)
+#endif
 #define TS_STORE(ptr)
 #endif
 struct DevRes {
@@ -357,7 +362,8 @@ __device__ __forceinline__ void tscatter_batch(const double *&vp, const int *&tp
   vp += U * WAVE; tp += U * WAVE;
 }
 // OCM: 0 the level loop below; 1 / 2 the on-chip topology without / with an arrow head: kernel_onchip.hpp's oc_ldl on the assembled blocks
-template <int NW, int OCM = 0>
+// TAIL: leave w = rho z - y behind (the set-up kernel of kernel_oc_split.hpp has no iterate yet: false)
+template <int NW, int OCM = 0, bool TAIL = true>
 __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullptr, const int *octab = nullptr, double *scr = nullptr) {
   const DevPlan &pl = *cx.pl; const DevRes &rs = *cx.rs; double *ws = cx.ws;
   const int wid = cx.wid, lane = cx.lane, tid = wid * WAVE + lane; constexpr int NT = NW * WAVE;
@@ -547,10 +553,12 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
     double *ni = cx.BL + (long)pl.nblk * BLK;
     for (int e = tid; e < BLK; e += NT) ni[e] = (e / BS == e % BS) ? -1.0 : 0.0;
   }
+  if constexpr (TAIL) {
   if (rs.tmp_alias) {   // the temp tiles lived in w: its rho vector is gone, recompute it (bit-identical) from the bounds
     for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = i < pl.m ? rho_of(lb[i], ub[i], cx.rho) * cx.Z[i] - cx.Y[i] : 0.0;
   } else {
     for (int i = tid; i < pl.mpad; i += NT) cx.W[i] = cx.W[i] * cx.Z[i] - cx.Y[i];
+  }
   }
   bsync<NW>();
 #ifdef MPCQP_TIMING

@@ -25,25 +25,9 @@
 // re-factorisation in-kernel; workgroup-uniform state in scalar registers (uni()).
 // Numerics are fp64 throughout and follow oracle/osqp_oracle.c step by step (same scaling rule, rho rule,
 // termination / infeasibility tests and deterministic adaptive-rho schedule).
-#include <hip/hip_runtime.h>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <map>
 #include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/mpcqp.h"
-#include "plan.hpp"
-#include "common.hpp"
-
-using namespace mpcqp;
-#include "kernels_common.hpp"
-#include "kernel_stream.hpp"
-#include "kernel_onchip.hpp"
-#include "kernel_resident.hpp"
+#include "kernels_all.hpp"
 #include "kernels_util.hpp"
 #include "reduced.hpp"
 
@@ -83,7 +67,9 @@ struct mpcqp_handle {
   bool stream_pd8 = false;      // streaming kernel instance (read from the environment once, at create)
   bool occ4 = false;            // ... its 128-VGPR instance (>= 3 workgroups per CU fit in LDS)
   bool oc = false;              // on-chip mode of the global-block kernel (kernel_onchip.hpp): two workgroups per CU, factor in LDS + registers
-  int oc8 = 0;                  // ... its eight-wave instances for long chains (one workgroup per CU): 1 = <NG 4, NH 4>, 2 = <NG 7, NH 5, z / y in the slab>
+  int oc8 = 0;                  // ... its eight-wave instances for long chains (one workgroup per CU): 1 = <NG 4, NH 4>, 2 = <NG 7, NH 7>
+  int resume_rounds = 1;        // two-kernel form: {re-factorisation, iteration} pairs queued behind a solve before the last pair (MPCQP_RESUME_ROUNDS)
+  bool split = false;           // ... as two kernels, set-up and iteration (kernel_oc_split.hpp): the default; MPCQP_OC_MONO=1 and the tile experiment keep the single kernel
   OcPlan ocplan; DevOc doc;
   TilePlan tplan; bool tiles = false;   // on-chip kernels: dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan)
   ResPlan rplan; DevRes dres;
@@ -102,6 +88,7 @@ struct mpcqp_handle {
   long long *odbg = nullptr;
   bool have_data = false, solved = false;
   hipStream_t last_stream = nullptr;
+  hipEvent_t ev_mid = nullptr;                // two-kernel on-chip mode: between the set-up and the iteration kernel (mpcqp_last_phase_ms)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev0r = nullptr;   // (ev0r: reduced handles, ordering of the presolve behind a solve on another stream)
   // reduced form (mpcqp_create_reduced): this handle keeps the caller's dimensions, `inner` solves the QP without the eliminated variables
   mpcqp_handle *inner = nullptr; RedMaps red; DevRed dred; double *rx0 = nullptr, *ry0 = nullptr;
@@ -135,42 +122,54 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
   return MPCQP_OK;
 }
 
-// register-resident blocks per wave of the on-chip instance: inverse diagonal blocks (positions per wave) and hub blocks
-constexpr int OC_NG = 5, OC_NH = 3;
-constexpr long OC_LDS_MAX = 80 * 1024;      // two workgroups per CU
-// Long chains (more than 20 chain blocks: quadrotor N > 20, cart-pole N > 60): eight waves per QP, one workgroup per CU -- the whole LDS and
-// 8 x 256 VGPRs for one factor.  Two instances: up to 32 chain blocks with every hub block in registers (cart-pole N = 100: 62 KB of chain
-// blocks + 36 KB of vectors in LDS), and up to 56 with seven positions per wave, G_p and every hub block (both orientations) in registers --
-// 168 resident VGPRs -- and only the chain blocks and the hub's inverse in LDS (quadrotor N = 50: 50 blocks = 100 KB + 57 KB of vectors and
-// tables = 159,880 B).  (Measured against <NG 7, NH 5> with z, y in the slab, 157,832 B and 136 resident VGPRs: 35.5 against 35.9 ms and an
-// eighth less HBM traffic -- the slab vectors cost more than the extra spills.)
-struct Oc8Inst { int ng, nh; bool zyg; };
-constexpr Oc8Inst OC8_INST[2] = {{4, 4, false}, {7, 7, false}};
-constexpr long OC8_LDS_MAX = 160 * 1024;
+constexpr long OC_LDS_MAX = 80 * 1024;      // four-wave on-chip instances: two workgroups per CU
+constexpr long OC8_LDS_MAX = 160 * 1024;    // eight-wave ones: one (kernel_table.hpp OC8_INST)
 constexpr int OC8_MAX_CHAIN = 64;           // (oc_ldl keeps the chain's block ids one per lane)
 
-// the kernel instance a handle runs: waves per QP, register budget, factor location, and -- as its own instance so that the
-// full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
-template <bool REUSE>
-static const void *res_kernel_pick(const mpcqp_handle *h) {
-  if (h->oc && h->tiles && h->oc8 == 1) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[0].zyg, OC8_INST[0].ng, OC8_INST[0].nh, true>;
-  if (h->oc && h->tiles && h->oc8 == 2) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh, true>;
-  if (h->oc && h->tiles) return (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH, true>;
-  if (h->oc && h->oc8 == 1) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[0].zyg, OC8_INST[0].ng, OC8_INST[0].nh>;
-  if (h->oc && h->oc8 == 2) return (const void *)mpcqp_res_kernel<8, 2, true, REUSE, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh>;
-  if (h->oc) return h->ocplan.has_hub ? (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, OC_NH> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, false, OC_NG, 0>;
-  if (h->gblocks && h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, true, REUSE>;
-  if (h->gblocks && h->zyg) return h->occ3 ? (const void *)mpcqp_res_kernel<4, 3, true, REUSE, true> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE, true>;
-  if (h->gblocks && h->occ3) return (const void *)mpcqp_res_kernel<4, 3, true, REUSE>;
-  if (h->gblocks) return h->occ4 ? (const void *)mpcqp_res_kernel<4, 4, true, REUSE> : (const void *)mpcqp_res_kernel<4, 2, true, REUSE>;
-  if (h->variant == 1) return h->res1x ? (const void *)mpcqp_res_kernel<1, 4, false, REUSE> : (const void *)mpcqp_res_kernel<1, 2, false, REUSE>;
-  if (h->variant == 8) return (const void *)mpcqp_res_kernel<8, 2, false, REUSE>;
-  if (h->variant == 2) return (const void *)mpcqp_res_kernel<2, 3, false, REUSE>;
-  if (h->res3 == 4) return (const void *)mpcqp_res_kernel<4, 4, false, REUSE>;
-  if (h->res3 == 3) return (const void *)mpcqp_res_kernel<4, 3, false, REUSE>;
-  return h->wide ? (const void *)mpcqp_res_kernel<4, 1, false, REUSE> : (const void *)mpcqp_res_kernel<4, 2, false, REUSE>;
+// the kernel instance a handle runs (instantiated in the k_*.hip units, kernel_table.hpp): waves per QP, register budget, factor location, and --
+// as its own instance so that the full-setup kernels carry no code for it -- the kept-workspace entry (mpcqp_update_vectors)
+static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
+  auto lds = [&](int nw, int minw) { return reuse ? mpcqp_kernel_res_lds_r1(nw, minw) : mpcqp_kernel_res_lds_r0(nw, minw); };
+  auto gb = [&](int nw, int minw, bool zyg) { return reuse ? mpcqp_kernel_res_gb_r1(nw, minw, zyg) : mpcqp_kernel_res_gb_r0(nw, minw, zyg); };
+  auto mono = [&](int nw, int ng, int nh) { return reuse ? mpcqp_kernel_oc_mono_r1(nw, ng, nh, h->tiles) : mpcqp_kernel_oc_mono_r0(nw, ng, nh, h->tiles); };
+  if (h->oc && h->oc8) return mono(8, OC8_INST[h->oc8 - 1].ng, OC8_INST[h->oc8 - 1].nh);
+  if (h->oc) return mono(4, OC_NG, h->ocplan.has_hub ? OC_NH : 0);
+  if (h->gblocks && h->variant == 2) return gb(2, 3, false);
+  if (h->gblocks && h->zyg) return gb(4, h->occ3 ? 3 : 2, true);
+  if (h->gblocks && h->occ3) return gb(4, 3, false);
+  if (h->gblocks) return gb(4, h->occ4 ? 4 : 2, false);
+  if (h->variant == 1) return lds(1, h->res1x ? 4 : 2);
+  if (h->variant == 8) return lds(8, 2);
+  if (h->variant == 2) return lds(2, 3);
+  if (h->res3 == 4) return lds(4, 4);
+  if (h->res3 == 3) return lds(4, 3);
+  return lds(4, h->wide ? 1 : 2);
 }
-static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) { return reuse ? res_kernel_pick<true>(h) : res_kernel_pick<false>(h); }
+// the two kernels of the on-chip mode (kernel_oc_split.hpp): CuCaQP::initSolver and CuCaQP::solve
+static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->oc8 ? 8 : 4, h->ocplan.has_hub != 0, reuse); }
+static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
+  const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = h->oc8 ? OC8_INST[h->oc8 - 1].nh : (h->ocplan.has_hub ? OC_NH : 0);
+  return rf ? mpcqp_kernel_oc_admm_rf(nw, ng, nh) : mpcqp_kernel_oc_admm(nw, ng, nh);
+}
+// One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
+// (kernel_oc_split.hpp: they leave the iteration kernel marked OC_PENDING), `resume_rounds` pairs of {re-factorisation, iteration} in which every other
+// workgroup returns at once, and a last pair whose iteration kernel re-factorises in place, so that any number of rho updates is served.
+static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, bool mark) {
+  const dim3 grid(count), block(h->variant * WAVE);
+  DevOc docr = h->doc; docr.resume = 1;
+  void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
+  void *argr[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&docr};
+  HIPCHK(hipLaunchKernel(oc_setup_of(h, reuse), grid, block, args, (size_t)h->lds, s));
+  if (mark) HIPCHK(hipEventRecord(h->ev_mid, s));
+  const bool rho_updates = h->st.adaptive_rho != 0;
+  HIPCHK(hipLaunchKernel(oc_admm_of(h, !rho_updates), grid, block, args, (size_t)h->lds, s));     // (without adaptive rho nothing ever leaves: either instance serves)
+  if (!rho_updates) return MPCQP_OK;
+  for (int r = 0; r <= h->resume_rounds; r++) {
+    HIPCHK(hipLaunchKernel(oc_setup_of(h, false), grid, block, argr, (size_t)h->lds, s));
+    HIPCHK(hipLaunchKernel(oc_admm_of(h, r == h->resume_rounds), grid, block, argr, (size_t)h->lds, s));
+  }
+  return MPCQP_OK;
+}
 
 extern "C" {
 
@@ -401,7 +400,10 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
-      if (getenv("MPCQP_LATE") && !h->tiles) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
+      // (single-kernel four-wave instance only: the eight-wave solve, oc_solve_long, has no ticket wait, and the two-kernel form sweeps all of A' up front)
+      h->split = !h->tiles && !getenv("MPCQP_OC_MONO");
+      if (const char *e = getenv("MPCQP_RESUME_ROUNDS")) h->resume_rounds = std::max(0, std::min(atoi(e), 8));
+      if (getenv("MPCQP_LATE") && !h->tiles && !h->oc8 && !h->split) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));
@@ -459,10 +461,12 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     // MaxDynamicSharedMemorySize is a property of the kernel function, shared by every handle that launches it: keep a running
     // maximum per function so that a later handle with a smaller footprint never lowers the limit under an earlier one
     static std::mutex mu; static std::map<std::pair<const void *, int>, long> limit;   // (function, device)
-    const void *fns[2] = {res_kernel_of(h, false), res_kernel_of(h, true)};
+    const void *fns[4] = {res_kernel_of(h, false), res_kernel_of(h, true), nullptr, nullptr};
     if (h->variant == 0) fns[0] = fns[1] = h->stream_pd8 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>;
+    if (h->split) { fns[0] = oc_setup_of(h, false); fns[1] = oc_setup_of(h, true); fns[2] = oc_admm_of(h, false); fns[3] = oc_admm_of(h, true); }
     std::lock_guard<std::mutex> lock(mu);
     for (const void *fn : fns) {
+      if (!fn) continue;
       long &cur = limit[{fn, h->device}];
       if (h->lds <= cur) continue;
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
@@ -470,7 +474,17 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       cur = h->lds;
     }
   }
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
+  if (h->variant > 0 && !(h->split ? oc_setup_of(h, false) && oc_setup_of(h, true) && oc_admm_of(h, false) && oc_admm_of(h, true) : res_kernel_of(h, false) && res_kernel_of(h, true)))
+    return bail(fail(MPCQP_ERR_STATE, "no kernel instance for this handle (kernel_table.hpp)"));
+  if (h->split) {     // the kernel arguments once more in global memory, for code that runs out of line (kernel_oc_split.hpp OcCold)
+    std::vector<OcCold> cold(1);
+    cold[0].pl = h->dp; cold[0].rs = h->dres; cold[0].st = h->st; cold[0].oc = h->doc; cold[0].oc.cold = nullptr;
+    const OcCold *dc = nullptr;
+    int rc = upload(h, cold, &dc);
+    if (rc) return bail(rc);
+    h->doc.cold = dc;
+  }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_mid) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
   h->lpt = !getenv("MPCQP_NO_LPT");
   {   // dispatch-hint buffers up front: nothing is allocated inside mpcqp_solve, so a solve can be captured in a HIP graph
@@ -753,7 +767,11 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
   HIPCHK(hipEventRecord(h->ev0, s));
-  if (h->variant > 0) {
+  if (h->variant > 0 && h->split) {     // CuCaQP::initSolver, then CuCaQP::solve
+    int rc = launch_oc_split(h, io, h->batch, io.reuse != 0, s, true);
+    if (rc) return rc;
+  }
+  else if (h->variant > 0) {
     void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, io.reuse != 0), dim3(h->batch), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
@@ -788,7 +806,11 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
   io.ws += (long)b0 * h->dp.ws_stride; io.cscale += b0;
   if (io.dbg) io.dbg += 16L * b0;
   io.order = nullptr;
-  if (h->variant > 0) {
+  if (h->variant > 0 && h->split) {
+    int rc = launch_oc_split(h, io, count, false, s, false);
+    if (rc) return rc;
+  }
+  else if (h->variant > 0) {
     void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
     HIPCHK(hipLaunchKernel(res_kernel_of(h, false), dim3(count), dim3(h->variant * WAVE), args, (size_t)h->lds, s));
   }
@@ -896,6 +918,7 @@ void mpcqp_destroy(mpcqp_handle *h) {
   for (void *p : h->dev_allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->ev0r) (void)hipEventDestroy(h->ev0r);
   for (int i = 0; i < mpcqp_handle::NPIPE; i++) if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);
@@ -911,6 +934,18 @@ int mpcqp_last_kernel_ms(mpcqp_handle *h, float *ms) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return MPCQP_OK;
+}
+
+int mpcqp_last_phase_ms(mpcqp_handle *h, float *setup_ms, float *solve_ms) {
+  if (!h || !setup_ms || !solve_ms) return fail(MPCQP_ERR_ARG, "null pointer");
+  if (!h->solved) return fail(MPCQP_ERR_STATE, "no solve has been issued");
+  if (h->inner) return mpcqp_last_phase_ms(h->inner, setup_ms, solve_ms);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  if (!h->split) { *setup_ms = 0.f; HIPCHK(hipEventElapsedTime(solve_ms, h->ev0, h->ev1)); return MPCQP_OK; }
+  HIPCHK(hipEventElapsedTime(setup_ms, h->ev0, h->ev_mid));
+  HIPCHK(hipEventElapsedTime(solve_ms, h->ev_mid, h->ev1));
   return MPCQP_OK;
 }
 
