@@ -25,6 +25,31 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 FP64_VEC_PEAK_TFLOPS = 78.6
+LDS_PEAK_GBS = 150000.0    # every CU streaming ds_read_b64 / b128: 256 B/clk/CU x 256 CUs at ~2.4 GHz (same guide, section LDS)
+MFMA_F64_4X4_DEP_CYCLES = 52   # a v_mfma_f64_4x4x4_4b_f64 that waits for the previous one's accumulator (tools/probes/mfma_4x4_probe.hip)
+SHADER_CLOCK_GHZ = 2.4
+CUS = 256
+
+
+def onchip_rooflines(pinfo, ocinfo, n, m, batch, iters_mean, kernel_ms):
+    """SURVEY.md section 8(d) beyond HBM, for the on-chip kernels: the LDS-bandwidth fraction and the share of a QP's residence that is the
+    dependent MFMA chain of the two triangular sweeps.  ALGORITHMIC LDS bytes of one ADMM iteration: every factor block
+    that lives in LDS read once per sweep direction (2 x 2 KiB), one 8-byte gathered operand per ELL slot entry of A and A', and the iterate
+    vectors (x, q, r twice in the solve: 8 passes over npad; z, y, w: 6 over mpad).  mfma_issue_frac: per iteration each sweep walks the longer chain
+    position by position, 4 dependent 4x4x4 MFMAs each, at the dependent issue interval, over the cycles a QP is resident (kernel time x the QPs a CU
+    holds at once)."""
+    if pinfo["variant"] < 200:
+        return None, None
+    nw = pinfo["variant"] - 200
+    lds_iter = 8 * (2 * ocinfo["lds_blocks"] * 256 + (ocinfo["slots_A"] + ocinfo["slots_At"]) * 64 + 8 * pinfo["npad"] + 6 * pinfo["mpad"])
+    ach = lds_iter * iters_mean * batch / (kernel_ms * 1e-3) / 1e9
+    lds = {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBS, "algorithmic_lds_bytes_per_admm_iter": lds_iter}
+    resident = CUS * (2 if nw == 4 else 1)
+    cycles_per_qp = kernel_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9 * min(resident, batch) / batch
+    stages = 2 * max(ocinfo["chain_e"], ocinfo["chain_f"])
+    dep = iters_mean * stages * 4 * MFMA_F64_4X4_DEP_CYCLES
+    return lds, {"value": dep / cycles_per_qp, "dependent_mfma_cycles_per_admm_iter": stages * 4 * MFMA_F64_4X4_DEP_CYCLES, "chain_positions": max(ocinfo["chain_e"], ocinfo["chain_f"]),
+                 "resident_cycles_per_qp": cycles_per_qp, "note": "chains of the forward and backward sweep: 4 dependent v_mfma_f64_4x4x4_4b_f64 per position at %d cycles, over kernel time x QPs resident per CU (%d) at %.1f GHz" % (MFMA_F64_4X4_DEP_CYCLES, 2 if nw == 4 else 1, SHADER_CLOCK_GHZ)}
 
 
 def host_cores():
@@ -72,8 +97,9 @@ def committed_traffic(key):
     return e.get("hbm_bytes_per_launch")
 
 
-def one_config(workload, N, batch, seed, dev, steps=2):
-    """one warmed step of another BASELINE configuration (same step as the timed region: update + solve + get, instances in batch order)"""
+def one_config(workload, N, batch, seed, dev, steps=5):
+    """another BASELINE configuration: one warm-up step, then `steps` timed ones (same step as the timed region of `value`: update + solve + get, instances in
+    batch order); value from the MEDIAN step"""
     import torch
     from optimal_control_problem_amd import models
     from optimal_control_problem_amd.batch_qp import BatchQP
@@ -89,20 +115,27 @@ def one_config(workload, N, batch, seed, dev, steps=2):
     def step():
         qp.update(*d); qp.solve(stream); qp.get_device(x=ox, y=oy, status=ost, iters=oit)
     step(); torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:      # (events read after the loop: see the timed region of main)
-        qp.update(*d); e0.record(); qp.solve(stream); e1.record(); qp.get_device(x=ox, y=oy, status=ost, iters=oit)
+    # every step between its own pair of events on the launch stream (whole step: update + solve + get), read after the loop -- waiting inside it
+    # would park the host once per step; a second pair around the solve alone for the kernels' time
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
+    for a, e0, e1, b in evs:
+        a.record(); qp.update(*d); e0.record(); qp.solve(stream); e1.record(); qp.get_device(x=ox, y=oy, status=ost, iters=oit); b.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    kms = [e0.elapsed_time(e1) for e0, e1 in evs]
-    pinfo = qp.plan_info()
+    dts = [a.elapsed_time(b) * 1e-3 for a, _, _, b in evs]
+    dt = float(np.median(dts))
+    kms = [e0.elapsed_time(e1) for _, e0, e1, _ in evs]
+    pinfo = qp.plan_info(); ocinfo = qp.oc_info()
     abytes = algorithmic_bytes_per_solve(pinfo["nnzP_triu"], pinfo["nnzA"], ls.n, ls.m)
-    k = float(np.mean(kms))
+    k = float(np.median(kms))
+    itm = float(oit.float().mean())
+    lds_roof, mfma_frac = onchip_rooflines(pinfo, ocinfo, ls.n, ls.m, batch, itm, k)
+    setup_ms, iter_ms = qp.last_phase_ms()
     out = {"workload": "%s horizon=%d batch=%d (n=%d m=%d)" % (mdl.name, N, batch, ls.n, ls.m), "value": batch / dt, "unit": "QP solves/s", "ms_per_step": dt * 1e3, "kernel_ms": k,
-           "mean_admm_iters": float(oit.float().mean()), "solved_frac": float((ost == 1).float().mean()), "variant": pinfo["variant"], "lds_bytes_per_qp": pinfo["lds_bytes"],
+           "steps": steps, "ms_per_step_all": [x * 1e3 for x in dts], "kernels_ms_last_step": {"setup (initSolver)": setup_ms, "iteration (solve)": iter_ms},
+           "mean_admm_iters": itm, "solved_frac": float((ost == 1).float().mean()), "variant": pinfo["variant"], "lds_bytes_per_qp": pinfo["lds_bytes"],
            "roofline": {"bound": "hbm", "achieved": abytes * batch / (k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes * batch / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_solve": abytes, "traffic": committed_traffic("%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"]))},
+                        "algorithmic_bytes_per_solve": abytes, "traffic": committed_traffic("%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"])),
+                        "lds": lds_roof, "mfma_issue_frac": mfma_frac},
            "workload_gen_s": t_gen}
     qp.close()
     del d, ox, oy
@@ -110,7 +143,7 @@ def one_config(workload, N, batch, seed, dev, steps=2):
     return out
 
 
-def sqp_iteration_device(workload, N, batch, seed, dev, reps=3):
+def sqp_iteration_device(workload, N, batch, seed, dev, reps=5):
     """the complete device-resident SQP iteration on the headline workload (SURVEY.md section 8d's metric with the producer inside the step,
     reference SQPOptimizationSolver.cpp:137-198): mpcqp_stage_eval -> mpcqp_update -> mpcqp_solve -> mpcqp_get -> mpcqp_stage_step / merit,
     from the seeded iterate every time, nothing crossing PCIe"""
@@ -127,8 +160,8 @@ def sqp_iteration_device(workload, N, batch, seed, dev, reps=3):
     for _ in range(reps):
         sq.setInitialGuess(x0); torch.cuda.synchronize()
         t0 = time.perf_counter(); sq.getOptimalSolution(arg, to_host=False); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    dt = float(np.mean(ts))
-    out = {"value": batch / dt, "unit": "QP solves/s (one SQP iteration each, evaluation included)", "ms_per_iteration": dt * 1e3, "qp_kernel_ms": sq.qp.last_kernel_ms(),
+    dt = float(np.median(ts))
+    out = {"value": batch / dt, "unit": "QP solves/s (one SQP iteration each, evaluation included)", "ms_per_iteration": dt * 1e3, "repetitions": reps, "ms_all": [t * 1e3 for t in ts], "qp_kernel_ms": sq.qp.last_kernel_ms(),
            "mean_admm_iters": float(sq.iters.float().mean()), "solved_frac": float((sq.status == 1).float().mean()),
            "steps": "mpcqp_stage_eval + mpcqp_update + mpcqp_solve + mpcqp_get + mpcqp_stage_step + mpcqp_stage_merit, inputs and iterate resident in HBM, instances in batch order"}
     sq.close()
@@ -207,7 +240,7 @@ def main():
     # (mpcqp_set_dispatch_hint, on by default in the library) predicts from the previous solve of the same handle; this
     # loop re-solves one batch, which would make that prediction exact, so it is reported separately (with_dispatch_hint).
     qp.set_dispatch_hint(False)
-    pinfo = qp.plan_info()
+    pinfo = qp.plan_info(); ocinfo = qp.oc_info()
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -235,7 +268,8 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist)
     kernel_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
-    kernel_ms_last_lib = qp.last_kernel_ms()         # the library's own events around the solve kernel alone, last step
+    kernel_ms_last_lib = qp.last_kernel_ms()         # the library's own events around the solve kernels alone, last step
+    setup_ms_last, iter_ms_last = qp.last_phase_ms()  # ... and split by the reference's two calls (on-chip mode: set-up kernel / iteration kernel)
 
     iters = oit.cpu().numpy(); status = ost.cpu().numpy()
     solved_local = int((status == 1).sum())
@@ -262,6 +296,7 @@ def main():
         flops_iter = 4 * pinfo["L_blocks"] * 256 + 2 * (2 * pinfo["nnzA"]) + 2 * (2 * pinfo["nnzP_triu"] - ls.n) + 12 * (ls.n + ls.m)
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command on this same build of the library, else null
         traffic = None if args.force_iters else committed_traffic("%s_N%d_b%d_variant%d" % (mdl.name, N, batch, pinfo["variant"]))
+        lds_roof, mfma_frac = onchip_rooflines(pinfo, ocinfo, ls.n, ls.m, batch, iters_sum / (world * batch), kms)
         out = {
             "metric": "QP solves/sec (batched OSQP-ADMM, N=%d)" % N, "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -275,7 +310,11 @@ def main():
                          # the same launch priced on its measured HBM traffic instead of the algorithmic bytes
                          "achieved_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9,
                          "frac_from_traffic": None if traffic is None else traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel": ("mpcqp_res_kernel (on-chip mode)" if pinfo["variant"] >= 200 else "mpcqp_res_kernel") if pinfo["variant"] else "mpcqp_admm_kernel", "kernel_ms": kms, "kernel_ms_max_over_ranks": kms_max, "kernel_ms_last_step_library_events": kernel_ms_last_lib,
+                         "kernel": ("mpcqp_oc_setup_kernel + mpcqp_oc_admm_kernel (on-chip mode; one launch each per solve, priced together: `achieved` divides by the sum of their durations)"
+                                    if pinfo["variant"] >= 200 and ocinfo["launch_pairs_for_rho_updates"] else "mpcqp_res_kernel (on-chip mode)" if pinfo["variant"] >= 200 else "mpcqp_res_kernel") if pinfo["variant"] else "mpcqp_admm_kernel",
+                         "kernels_ms_last_step": {"setup (CuCaQP::initSolver)": setup_ms_last, "iteration (CuCaQP::solve)": iter_ms_last}, "kernel_ms": kms,
+                         # the LDS-bandwidth fraction, and the share of a QP's residence spent in the dependent MFMA chains
+                         "lds": lds_roof, "mfma_issue_frac": mfma_frac, "kernel_ms_max_over_ranks": kms_max, "kernel_ms_last_step_library_events": kernel_ms_last_lib,
                          "algorithmic_bytes_per_solve": abytes,
                          # flops of one ADMM iteration = two block-triangular solves + A x, A'y + P x + vector work
                          "algorithmic_flops_per_admm_iter": flops_iter,

@@ -191,6 +191,14 @@ int mpcqp_last_phase_ms(mpcqp_handle *h, float *setup_ms, float *solve_ms);
  * the factor blocks left in the HBM slab, 200 + NW = on-chip mode: factor in LDS + registers) */
 int mpcqp_plan_info(const mpcqp_handle *h, long *info16);
 
+/* What bench.py prices a launch of the on-chip mode with (variant 200 + NW; info[0..7] are zero for other kernel families).  info[0..7]: chain blocks of the factor, 1 if
+ * the pattern has an arrow head (the parameter block), lengths of the two elimination chains (the critical path of each triangular sweep: one
+ * dependent 16 x 16 mat-vec per position), factor blocks resident in LDS, positions per wave, hub blocks per wave in registers, and -- two-kernel
+ * form -- the number of {re-factorisation, iteration} launch pairs queued behind a solve for adaptive-rho steps (0 = single kernel);
+ * info[8..10]: 64-lane ELL slots of A (by row), A' (by variable) and P that a sweep walks; info[11] reserved.  No reference counterpart (the
+ * reference's instruments are the two timers of SQPOptimizationSolver.cpp:133-164). */
+int mpcqp_oc_info(const mpcqp_handle *h, long *info12);
+
 /* Replaces CuCaQP::printSolverData (CuCaQP.cpp:226-269): copies the scaled problem data the kernel holds
  * for instance b back to the host (D [n], E [m], c; any pointer may be NULL). */
 int mpcqp_debug_scaling(mpcqp_handle *h, int b, double *D, double *E, double *c);

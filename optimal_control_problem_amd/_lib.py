@@ -16,7 +16,7 @@ STATUS = {1: "solved", 2: "solved_inaccurate", 3: "primal_infeasible", 4: "prima
 
 EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_create_tuned", "mpcqp_create_reduced", "mpcqp_update", "mpcqp_warm_start", "mpcqp_keep_workspace", "mpcqp_update_vectors", "mpcqp_set_rho", "mpcqp_set_dispatch_hint", "mpcqp_solve", "mpcqp_solve_host",
            "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms", "mpcqp_last_phase_ms",
-           "mpcqp_plan_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
+           "mpcqp_plan_info", "mpcqp_oc_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
            "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_set_path_bounds", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
            "mpcqp_stage_eval", "mpcqp_stage_merit", "mpcqp_stage_step",
            "mpcqp_stageqp_pattern", "mpcqp_stageqp_create", "mpcqp_stageqp_handle", "mpcqp_stageqp_update", "mpcqp_stageqp_destroy"]
@@ -87,6 +87,7 @@ def lib():
         L.mpcqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.mpcqp_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mpcqp_plan_info.argtypes = [vp, vp]
+        L.mpcqp_oc_info.argtypes = [vp, vp]
         L.mpcqp_debug_scaling.argtypes = [vp, C.c_int, dp, dp, dp]
         L.mpcqp_debug_blockops.argtypes = [dp, dp, dp, dp, dp, dp, vp]
         L.mpcqp_stageqp_pattern.argtypes = [vp, vp, vp, vp, vp, vp]

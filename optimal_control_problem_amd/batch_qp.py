@@ -195,6 +195,19 @@ class BatchQP:
         _lib.check(_lib.lib().mpcqp_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def last_phase_ms(self):
+        """(set-up kernel ms, iteration kernel ms) of the last solve where the handle runs them as two kernels (the on-chip mode), else (0, whole kernel)"""
+        a, b = C.c_float(), C.c_float()
+        _lib.check(_lib.lib().mpcqp_last_phase_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def oc_info(self):
+        """chain / hub shape of the on-chip mode's factor (all zero for other kernel families): what bench.py prices the chains with"""
+        a = np.zeros(12, dtype=np.int64)
+        _lib.check(_lib.lib().mpcqp_oc_info(self._h, a.ctypes.data))
+        return dict(zip(["chain_blocks", "has_hub", "chain_e", "chain_f", "lds_blocks", "positions_per_wave", "hub_blocks_in_registers", "launch_pairs_for_rho_updates",
+                         "slots_A", "slots_At", "slots_P"], a.tolist()))
+
     def plan_info(self):
         a = np.zeros(16, dtype=np.int64)
         _lib.check(_lib.lib().mpcqp_plan_info(self._h, a.ctypes.data))

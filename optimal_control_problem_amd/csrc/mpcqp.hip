@@ -154,13 +154,14 @@ static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
 // One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
 // (kernel_oc_split.hpp: they leave the iteration kernel marked OC_PENDING), `resume_rounds` pairs of {re-factorisation, iteration} in which every other
 // workgroup returns at once, and a last pair whose iteration kernel re-factorises in place, so that any number of rho updates is served.
-static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, bool mark) {
+static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, hipEvent_t after_setup) {
   const dim3 grid(count), block(h->variant * WAVE);
-  DevOc docr = h->doc; docr.resume = 1;
-  void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&h->doc};
+  DevOc doc0 = h->doc; doc0.resume = 0;
+  DevOc docr = doc0; docr.resume = 1;
+  void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&doc0};
   void *argr[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&docr};
   HIPCHK(hipLaunchKernel(oc_setup_of(h, reuse), grid, block, args, (size_t)h->lds, s));
-  if (mark) HIPCHK(hipEventRecord(h->ev_mid, s));
+  if (after_setup) HIPCHK(hipEventRecord(after_setup, s));
   const bool rho_updates = h->st.adaptive_rho != 0;
   HIPCHK(hipLaunchKernel(oc_admm_of(h, !rho_updates), grid, block, args, (size_t)h->lds, s));     // (without adaptive rho nothing ever leaves: either instance serves)
   if (!rho_updates) return MPCQP_OK;
@@ -170,7 +171,6 @@ static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hi
   }
   return MPCQP_OK;
 }
-
 extern "C" {
 
 void mpcqp_default_settings(mpcqp_settings *s) {
@@ -768,7 +768,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
   HIPCHK(hipEventRecord(h->ev0, s));
   if (h->variant > 0 && h->split) {     // CuCaQP::initSolver, then CuCaQP::solve
-    int rc = launch_oc_split(h, io, h->batch, io.reuse != 0, s, true);
+    int rc = launch_oc_split(h, io, h->batch, io.reuse != 0, s, h->ev_mid);
     if (rc) return rc;
   }
   else if (h->variant > 0) {
@@ -807,7 +807,7 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
   if (io.dbg) io.dbg += 16L * b0;
   io.order = nullptr;
   if (h->variant > 0 && h->split) {
-    int rc = launch_oc_split(h, io, count, false, s, false);
+    int rc = launch_oc_split(h, io, count, false, s, nullptr);
     if (rc) return rc;
   }
   else if (h->variant > 0) {
@@ -956,6 +956,17 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
   o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = h->oc ? (h->tiles ? h->tplan.ntile : 0) : (long)pl.fac.size();
   o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->oc ? 200 + h->variant : h->gblocks ? 100 + h->variant : h->variant;
+  return MPCQP_OK;
+}
+
+int mpcqp_oc_info(const mpcqp_handle *h, long *o) {
+  if (!h || !o) return fail(MPCQP_ERR_ARG, "null pointer");
+  if (h->inner) return mpcqp_oc_info(h->inner, o);
+  for (int k = 0; k < 12; k++) o[k] = 0;
+  o[8] = h->plan.A.slots(); o[9] = h->plan.At.slots(); o[10] = h->plan.P.slots();
+  if (!h->oc) return MPCQP_OK;
+  const OcPlan &p = h->ocplan;
+  o[0] = p.nbc; o[1] = p.has_hub; o[2] = (long)p.chainE.size(); o[3] = (long)p.chainF.size(); o[4] = p.nlds; o[5] = p.npw; o[6] = p.nhr; o[7] = h->split ? 1 + h->resume_rounds : 0;
   return MPCQP_OK;
 }
 

@@ -14,7 +14,8 @@ def shard_range(total, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-INIT_TIMEOUT_S = 180       # rendezvous + communicator set-up; a rank that cannot join ends with a one-line reason instead of hanging the job
+INIT_TIMEOUT_S = 180       # rendezvous + communicator set-up + the first collective; a rank that cannot join ends with a one-line reason instead of hanging the job
+GROUP_TIMEOUT_S = 1800     # every later collective (the group's own timeout): ranks may be minutes apart, e.g. one of them rebuilding the library
 
 
 def init_distributed(n_gpus, backend=None):
@@ -35,12 +36,23 @@ def init_distributed(n_gpus, backend=None):
     if not dist.is_initialized():
         import datetime
         import sys
+        import threading
+
+        def give_up():      # the join watchdog: only the rendezvous and the first collective are under the short limit, not the group
+            print("sharding: rank %d of %d could not join the %s group on %s:%s within %d s" % (rank, world, backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), INIT_TIMEOUT_S),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(INIT_TIMEOUT_S, give_up); watchdog.daemon = True; watchdog.start()
         try:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
-            # the first collective is where a broken RCCL set-up shows (communicators are created lazily): do it here, under the timeout
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
+            # the first collective is where a broken RCCL set-up shows (communicators are created lazily): do it here, under the watchdog
             t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
             dist.all_reduce(t)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+            watchdog.cancel()
         except Exception as e:      # noqa: BLE001 -- whatever the backend raises
+            watchdog.cancel()
             print("sharding: rank %d of %d could not join the %s group on %s:%s: %s" % (rank, world, backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
                                                                                        str(e).splitlines()[0] if str(e) else type(e).__name__), file=sys.stderr, flush=True)
             raise SystemExit(3)

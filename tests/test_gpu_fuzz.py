@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.support.problems import sparse_batch
+from tests.support.problems import random_stage_ocp, sparse_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -92,4 +92,70 @@ def test_random_patterns_every_family(built, monkeypatch):
     print("tolerance-level instances per family:", report, "worst residual ratio gpu / oracle among them: %.2f" % worst)
     for fam, s in stats.items():
         assert s["solves"] > 0, fam
+        assert s["soft"] <= 0.03 * s["solves"], (fam, report)
+
+
+OC_FAMILIES = [("oc4", 204), ("oc8", 208)]
+OC_NPAT = 20
+
+
+def test_random_stage_patterns_onchip_families(built, monkeypatch):
+    """The same gate for the families that are the DEFAULT on the north-star workload and on BASELINE configs 3, 4, 5 -- the on-chip kernels, which
+    only take block-tridiagonal + arrow patterns and so never see the random patterns above: a 20-pattern slice of tools/fuzz_oc.py per family
+    (random nx / nu / N / weights / dynamics / iterate), a cold solve and a kept-workspace solve (new q, shifted bounds) each, under the
+    reference's settings (src/sqp_solver/SQPOptimizationSolver.cpp:81-85)."""
+    from optimal_control_problem_amd import _lib
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    from oracle import oracle as orc
+    stats = {f: dict(solves=0, soft=0, cases=0) for f, _ in OC_FAMILIES}
+    worst = 0.0
+    for fam, code in OC_FAMILIES:
+        monkeypatch.setenv("MPCQP_VARIANT", fam)
+        c = 0
+        while stats[fam]["cases"] < OC_NPAT and c < 4 * OC_NPAT:
+            ls, dims, rng = random_stage_ocp(c, fam); c += 1
+            B = ls.batch
+            try:
+                qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+            except _lib.MpcqpError as e:
+                if e.code == _lib.ERR_LIMIT:      # outside the instance's limits (chain length, LDS): not a case
+                    continue
+                raise
+            assert qp.plan_info()["variant"] == code
+            stats[fam]["cases"] += 1
+            qp.keep_workspace(True)
+            st = orc.State(orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai), B, orc.default_settings())
+            q2 = ls.q * 1.2 + 0.05 * rng.normal(size=ls.q.shape); sh = 0.02 * rng.normal(size=ls.l.shape)
+            for leg in ("cold", "kept"):
+                if leg == "cold":
+                    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get()
+                    ref = st.solve(ls.P, ls.q, ls.A, ls.l, ls.u); q, l, u = ls.q, ls.l, ls.u
+                else:
+                    qp.update_vectors(q2, ls.l + sh, ls.u + sh); qp.solve(); got = qp.get()
+                    ref = st.solve_vectors(q2, ls.l + sh, ls.u + sh); q, l, u = q2, ls.l + sh, ls.u + sh
+                tag = "%s case %d (%s) %s" % (fam, c - 1, dims, leg)
+                fin = np.isfinite(ref["x"])
+                assert (got["status"] == ref["status"]).all(), (tag, got["status"], ref["status"])
+                assert np.array_equal(np.isfinite(got["x"]), fin), tag
+                for b in range(B):
+                    stats[fam]["solves"] += 1
+                    if not fin[b].all():
+                        if got["iters"][b] != ref["iters"][b]:
+                            assert abs(int(got["iters"][b]) - int(ref["iters"][b])) <= 25, tag
+                            stats[fam]["soft"] += 1
+                        continue
+                    err = np.abs(got["x"][b] - ref["x"][b]).max() / (1 + np.abs(ref["x"][b]).max())
+                    if got["iters"][b] == ref["iters"][b] and err <= 1e-6:
+                        continue
+                    stats[fam]["soft"] += 1
+                    assert err <= 2e-2, (tag, b, err, got["iters"][b], ref["iters"][b])
+                    lsb = type(ls)(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P, q, ls.A, l, u)
+                    rg = _normalised_residual(lsb, b, got["x"][b], got["y"][b]); ro = _normalised_residual(lsb, b, ref["x"][b], ref["y"][b])
+                    worst = max(worst, rg / max(ro, 1e-300))
+                    assert rg <= max(1.0, 2.0 * ro) * (1 + 1e-9), (tag, b, rg, ro)
+            qp.close()
+    report = {f: "%d of %d solves, %d patterns" % (s["soft"], s["solves"], s["cases"]) for f, s in stats.items()}
+    print("on-chip families, tolerance-level instances:", report, "worst residual ratio gpu / oracle among them: %.2f" % worst)
+    for fam, s in stats.items():
+        assert s["cases"] == OC_NPAT, (fam, report)
         assert s["soft"] <= 0.03 * s["solves"], (fam, report)

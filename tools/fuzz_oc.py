@@ -15,29 +15,13 @@ import numpy as np
 from optimal_control_problem_amd import _lib, models
 from optimal_control_problem_amd.batch_qp import BatchQP
 from oracle import oracle as orc
+from tests.support.problems import random_stage_ocp
 
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tight = soft = bad = skipped = 0
 for c in range(ncase):
-    rng = np.random.default_rng(5000 + seed0 + c)
-    nx = int(rng.integers(2, 13)); nu = int(rng.integers(1, 5)); N = int(rng.integers(4, 26)); B = int(rng.integers(1, 6))
-    if FAMILY == "oc8":      # 21 ... 56 chain blocks of 16 variables
-        N = int(rng.integers((21 * 16) // (nx + nu) + 1, (56 * 16) // (nx + nu) + 1)); B = int(rng.integers(1, 4))
-    Am = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx)); Bm = 0.3 * rng.normal(size=(nx, nu)); w = rng.normal(size=nx)
-
-    class M(models.StageOCP):
-        name = "fuzz"
-        def F(self, s, u):
-            return s @ Am.T + u @ Bm.T + 0.05 * np.sin(s * w)
-        def frame_bounds(self):
-            return np.concatenate([np.full(nx, -5.0), np.full(nu, -1.0)]), np.concatenate([np.full(nx, 5.0), np.full(nu, 1.0)])
-    M.nx, M.nu = nx, nu
-    mdl = M(N, 0.05, rng.uniform(0.1, 10.0, nx), rng.uniform(0.01, 1.0, nu))
-    x = rng.normal(0, 0.3, (B, mdl.nvar)); p = rng.normal(0, 0.2, (B, nx))
-    lbx, ubx, lbg, ubg = mdl.stacked_bounds(x[:, :mdl.f].copy())
-    ls = mdl.local_system(p, x, lbx, ubx, lbg, ubg)
-    dims = "nx=%d nu=%d N=%d B=%d n=%d m=%d" % (nx, nu, N, B, ls.n, ls.m)
+    ls, dims, rng = random_stage_ocp(seed0 + c, FAMILY); B = ls.batch
     try:
         qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
     except _lib.MpcqpError as e:
