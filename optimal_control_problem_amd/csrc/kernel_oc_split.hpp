@@ -66,6 +66,112 @@ __device__ __forceinline__ void oc_tables_to_lds(const DevPlan &pl, const DevOc 
   cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
 }
 
+// ell_chunk with the gathers of a batch issued TOGETHER.  In ell_batch the compiler serialises "x = in[idx]; acc += v * x" slot by slot: wait for the
+// index, compute the LDS address, ds_read, wait for it (lgkmcnt(0)), fma -- one exposed LDS round trip of ~100 cycles per slot, 1,500 cycles for a
+// batch of 16 (measured with the MPCQP_TIMING_SWEEP build: issue of the 32 loads 1,512 cycles, wait for them 858, gathers + fma 1,552).  Here all U
+// LDS reads of a batch are in flight before the first fma (a compiler barrier between the two loops); the sum is still accumulated slot by slot in
+// ascending order with one fma each: the same bits.
+template <int U>
+__device__ __forceinline__ double ell_batch_g(const double *__restrict__ &vp, const int *__restrict__ &ip, const double *in, double acc) {
+  double v[U], x[U]; int ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) x[u] = in[ix[u]];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < U; u++) acc = __builtin_fma(v[u], x[u], acc);
+  vp += U * WAVE; ip += U * WAVE;
+  return acc;
+}
+template <int UMAX>
+__device__ __forceinline__ double ell_chunk_g(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
+  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
+  const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
+  double acc = 0.0;
+  int rem = s1 - s0;
+  if (UMAX >= 16) {
+    for (; rem >= 16; rem -= 16) acc = ell_batch_g<16>(vp, ip, in, acc);
+    if (rem & 8) acc = ell_batch_g<8>(vp, ip, in, acc);
+  } else {
+    for (; rem >= 8; rem -= 8) acc = ell_batch_g<8>(vp, ip, in, acc);
+  }
+  if (rem & 4) acc = ell_batch_g<4>(vp, ip, in, acc);
+  if (rem & 2) acc = ell_batch_g<2>(vp, ip, in, acc);
+  if (rem & 1) acc = ell_batch_g<1>(vp, ip, in, acc);
+  return acc;
+}
+
+// One wave's share of an ELL sweep as ONE stream of 8-slot batches that runs across the boundaries of its chunks: the loads of batch k + 1 are
+// issued before batch k is consumed.  The chunk-by-chunk form (ell_chunk) waits for a round trip to L2 / Infinity Cache / HBM per batch, one after
+// the other: a chunk of 20 slots is two of them, and every chunk starts a new one -- a wave with chunks of 1, 1 and 20 slots (A = [I; G]: the
+// identity rows fill chunks of one slot) spends four round trips, three of them on 2 + 4 slots.  Here a wave has its next batch in the air while it
+// multiplies, whatever chunk that belongs to, so a sweep costs about one round trip plus the arithmetic.
+//   * a batch is always 8 loads of values and 8 of indices; where a chunk has fewer slots left, the surplus loads go to the chunk's last slot once more
+//     (same lines: no traffic) and their values are zeroed -- straight-line code, exact wait counts;
+//   * the row sum is accumulated slot by slot in ascending order with one fma each, exactly as ell_chunk does it: the same bits;
+//   * head(c) is called when chunk c's first batch is issued -- what the row update needs from memory (l, u) travels with it -- and
+//     finish(c, sum, head's value) when its last batch has been added.
+// The two register sets of the pipeline take turns (no copy of a register with a load in flight).
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct EllBatch { double v[8]; int ix[8]; d2v hd; };
+struct EllPos { int c, s, e; };       // chunk, first slot of the batch, end of the chunk (workgroup-uniform per wave: scalar registers)
+template <int NW, class Head, class Finish>
+__device__ __forceinline__ void ell_stream_w(const int nchunks, const int *co, const double *__restrict__ val, const int *__restrict__ idx, const double *in,
+                                             const int wid, const int lane, Head &&head, Finish &&finish) {
+  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto issue = [&](EllBatch &b, const EllPos &p, const bool first) {
+    const int rem = p.e - p.s;
+    const long base = (long)p.s * WAVE + lane;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int o = max(min(u, rem - 1), 0) * WAVE;
+      b.v[u] = val[base + o]; b.ix[u] = idx[base + o];
+    }
+    if (first) b.hd = head(p.c);
+  };
+  auto next_of = [&](const EllPos &p) {
+    EllPos q = p;
+    q.s += 8;
+    if (q.s >= q.e) {
+      q.c += NW;
+      if (q.c < nchunks) { q.s = rfl(co[q.c]); q.e = rfl(co[q.c + 1]); }
+    }
+    return q;
+  };
+  double acc = 0.0;
+  auto consume = [&](const EllBatch &b, const EllPos &p) {
+    const int rem = p.e - p.s;
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = in[b.ix[u]];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = __builtin_fma(u < rem ? b.v[u] : 0.0, x[u], acc);
+    if (p.s + 8 >= p.e) { finish(p.c, acc, b.hd); acc = 0.0; }
+  };
+  EllPos p0; p0.c = wid;
+  if (p0.c >= nchunks) return;
+  p0.s = rfl(co[p0.c]); p0.e = rfl(co[p0.c + 1]);
+  EllBatch A, B;
+  A.hd = d2v{0, 0}; B.hd = d2v{0, 0};
+  issue(A, p0, true);
+  for (;;) {
+    const EllPos p1 = next_of(p0);
+    const bool more1 = p1.c < nchunks;
+    if (more1) { B.hd = A.hd; issue(B, p1, p1.c != p0.c); }      // (a batch of the same chunk carries the chunk's head value along)
+    __builtin_amdgcn_sched_barrier(0);
+    consume(A, p0);
+    if (!more1) break;
+    p0 = next_of(p1);
+    const bool more0 = p0.c < nchunks;
+    if (more0) { A.hd = B.hd; issue(A, p0, p0.c != p1.c); }
+    __builtin_amdgcn_sched_barrier(0);
+    consume(B, p1);
+    if (!more0) break;
+  }
+}
+
 // The re-factorisation of an adaptive-rho step, OUT OF LINE.  Inlined into the iteration kernel (as the single kernel has it) its register pressure
 // -- twelve operand tiles of the assembly, nine carried blocks of oc_ldl -- was behind 600 - 900 of that kernel's 700 - 1,100 spilled VGPRs although
 // it runs once in a hundred iterations, if at all.  As a function of its own it has its own allocation; the caller's resident blocks are dead across
@@ -261,7 +367,7 @@ template <int NW, int OCG, int OCH, int RF>
 __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
-  constexpr int OCU = NW == 4 ? 16 : 8;      // ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
+  [[maybe_unused]] constexpr int OCU = NW == 4 ? 16 : 8;      // ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
   constexpr bool HUB = OCH > 0;
   const int lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
@@ -338,15 +444,50 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
   if (ok) {
     int iter;
     for (iter = iter0 + 1; iter <= st.max_iter; iter++) {
+#ifdef MPCQP_TIMING_SWEEP
+      // diagnostic build: where the time of the A' sweep goes, wave by wave (first chunk of the wave, up to 16 slots): issue of the loads, wait for
+      // them, gathers + arithmetic + store, the rest of the wave's chunks, the barrier; slots 9 .. 13 of the QP's row, wave 0 (and wave NW - 1 in 14, 15)
+      {
+        const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+        const int ch0 = wid;
+        const int s0 = cx.coAt[ch0], s1 = cx.coAt[ch0 + 1];
+        double v[16]; int ix[16];
+        const long e0 = (long)s0 * WAVE + lane;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int o = max(min(u, s1 - s0 - 1), 0) * WAVE; v[u] = valAt[e0 + o]; ix[u] = pl.At.idx[e0 + o]; }      // (unconditional: a load under a branch makes the compiler wait for it at the join)
+        const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) a += (s0 + u < s1 ? v[u] : 0.0) * cx.W[ix[u]];
+        if (s1 - s0 > 16) a += ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, s0 + 16, s1, lane);
+        { const int t = ch0 * WAVE + lane; if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + a; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+        for (int ch = wid + NW; ch < pl.At.nchunks; ch += NW) {
+          const int t = ch * WAVE + lane;
+          const double vv = ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, cx.coAt[ch], cx.coAt[ch + 1], lane);
+          if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + vv;
+        }
+        const unsigned long long q4 = __builtin_amdgcn_s_memtime();
+        if (wid == 0) { ts_acc[9] += q1 - q0; ts_acc[10] += q2 - q1; ts_acc[11] += q3 - q2; ts_acc[12] += q4 - q3; }
+        if (wid == NW - 1) { cx.fts[2] += q2 - q0; cx.fts[3] += q4 - q2; }
+      }
+#elif defined(MPCQP_STREAM_SWEEP)
+      ell_stream_w<NW>(pl.At.nchunks, cx.coAt, valAt, pl.At.idx, cx.W, wid, lane, [&](const int) { return d2v{0, 0}; },
+                       [&](const int ch, const double v, const d2v) { const int t = ch * WAVE + lane; if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
+#else
       for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
         const int t = ch * WAVE + lane;
-        const double v = ell_chunk<false, OCU>(valAt, pl.At.idx, cx.W, cx.coAt[ch], cx.coAt[ch + 1], lane);
+        const double v = ell_chunk_g<OCU>(valAt, pl.At.idx, cx.W, cx.coAt[ch], cx.coAt[ch + 1], lane);
         if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
       }
+#endif
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
-#ifdef MPCQP_TIMING
+#if defined(MPCQP_TIMING) && !defined(MPCQP_TIMING_SWEEP)
       if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
       else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);
 #else
@@ -361,10 +502,17 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
         // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.  l, u are fetched before the row sum is
         // accumulated; rho_i and 1 / rho_i are selected from the three values the rho rule can produce (no per-row division).
         const double rho_eq = uni(Q_RHO_EQ * cx.rho), ri_min = 1.0 / Q_RHO_MIN, ri_eq = uni(1.0 / rho_eq), ri_in = uni(1.0 / cx.rho);
+#ifdef MPCQP_STREAM_SWEEP
+        ell_stream_w<NW>(pl.A.nchunks, cx.coA, valA, pl.A.idx, cx.R, wid, lane, [&](const int ch) { const int i = ch * WAVE + lane; return d2v{lb[i], ub[i]}; },
+                         [&](const int ch, const double zt, const d2v lu) {
+          const int i = ch * WAVE + lane;
+          const double lo = lu[0], up = lu[1];
+#else
         for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
           const int i = ch * WAVE + lane;
           const double lo = lb[i], up = ub[i];
-          const double zt = ell_chunk<false, OCU>(valA, pl.A.idx, cx.R, cx.coA[ch], cx.coA[ch + 1], lane);
+          const double zt = ell_chunk_g<OCU>(valA, pl.A.idx, cx.R, cx.coA[ch], cx.coA[ch + 1], lane);
+#endif
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
@@ -374,7 +522,11 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
             cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
             if (save) dyg[i] = dy;
           }
+#ifdef MPCQP_STREAM_SWEEP
+        });
+#else
         }
+#endif
       }
       bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
       if (__builtin_expect(save, 0)) {     // (its own loop: the address of dx stays out of the iteration's live set)
@@ -436,7 +588,13 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
     io.info[4L * b] = in.obj; io.info[4L * b + 1] = in.prim_res; io.info[4L * b + 2] = in.dual_res; io.info[4L * b + 3] = cx.rho;
   }
   TS(8);
-#ifdef MPCQP_TIMING
+#ifdef MPCQP_TIMING_SWEEP
+  // (wave NW - 1's stamps travel through LDS to the wave that stores the row)
+  if (wid == NW - 1 && lane == 0) { cx.RED[0] = (double)cx.fts[2]; cx.RED[1] = (double)cx.fts[3]; }
+  bsync<NW>();
+  ts_acc[13] = 0; ts_acc[14] = (unsigned long long)cx.RED[0]; ts_acc[15] = (unsigned long long)cx.RED[1];
+  if (tid == 0 && io.dbg) for (int k_ = 9; k_ < 16; k_++) io.dbg[16L * b + k_] = 0;
+#elif defined(MPCQP_TIMING)
   ts_acc[12] += cx.fts[0]; ts_acc[13] += cx.fts[1]; ts_acc[14] += cx.fts[2]; ts_acc[15] += cx.fts[3];
 #endif
   TS_STORE_ADD(io.dbg, 0, 16);
