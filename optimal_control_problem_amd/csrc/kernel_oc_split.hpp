@@ -66,6 +66,23 @@ __device__ __forceinline__ void oc_tables_to_lds(const DevPlan &pl, const DevOc 
   cx.coA = co; cx.coAt = co + pl.A.nchunks + 1; cx.coP = co + pl.A.nchunks + pl.At.nchunks + 2;
 }
 
+// This wave's chunk offsets of an ELL structure in the lanes of ONE register -- lane 2 k: first slot of its k-th chunk (chunk wid + k NW), lane 2 k + 1:
+// its end -- read once before the ADMM loop and picked out with v_readlane: the offsets used to come from LDS at the head of every chunk, a round trip
+// of ~120 cycles in front of the chunk's loads, six times per iteration on the north-star size.
+template <int NW>
+__device__ __forceinline__ int oc_my_chunks(const int *__restrict__ chunk_off, const int nchunks, const int wid, const int lane) {
+  const int c = wid + (lane >> 1) * NW;
+  return c < nchunks ? chunk_off[c + (lane & 1)] : 0;
+}
+// a workgroup-uniform double the compiler may not look through (it re-derived 1 / rho_i per lane and chunk from the rho it was selected from:
+// a twelve-instruction division sequence in every row update)
+__device__ __forceinline__ double opaque_uni(const double v) {
+  const long long b = __double_as_longlong(v);
+  unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)((unsigned long long)b >> 32);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // ell_chunk with the gathers of a batch issued TOGETHER.  In ell_batch the compiler serialises "x = in[idx]; acc += v * x" slot by slot: wait for the
 // index, compute the LDS address, ds_read, wait for it (lgkmcnt(0)), fma -- one exposed LDS round trip of ~100 cycles per slot, 1,500 cycles for a
 // batch of 16 (measured with the MPCQP_TIMING_SWEEP build: issue of the 32 loads 1,512 cycles, wait for them 858, gathers + fma 1,552).  Here all U
@@ -100,76 +117,6 @@ __device__ __forceinline__ double ell_chunk_g(const double *__restrict__ val, co
   if (rem & 2) acc = ell_batch_g<2>(vp, ip, in, acc);
   if (rem & 1) acc = ell_batch_g<1>(vp, ip, in, acc);
   return acc;
-}
-
-// One wave's share of an ELL sweep as ONE stream of 8-slot batches that runs across the boundaries of its chunks: the loads of batch k + 1 are
-// issued before batch k is consumed.  The chunk-by-chunk form (ell_chunk) waits for a round trip to L2 / Infinity Cache / HBM per batch, one after
-// the other: a chunk of 20 slots is two of them, and every chunk starts a new one -- a wave with chunks of 1, 1 and 20 slots (A = [I; G]: the
-// identity rows fill chunks of one slot) spends four round trips, three of them on 2 + 4 slots.  Here a wave has its next batch in the air while it
-// multiplies, whatever chunk that belongs to, so a sweep costs about one round trip plus the arithmetic.
-//   * a batch is always 8 loads of values and 8 of indices; where a chunk has fewer slots left, the surplus loads go to the chunk's last slot once more
-//     (same lines: no traffic) and their values are zeroed -- straight-line code, exact wait counts;
-//   * the row sum is accumulated slot by slot in ascending order with one fma each, exactly as ell_chunk does it: the same bits;
-//   * head(c) is called when chunk c's first batch is issued -- what the row update needs from memory (l, u) travels with it -- and
-//     finish(c, sum, head's value) when its last batch has been added.
-// The two register sets of the pipeline take turns (no copy of a register with a load in flight).
-typedef double d2v __attribute__((ext_vector_type(2)));
-struct EllBatch { double v[8]; int ix[8]; d2v hd; };
-struct EllPos { int c, s, e; };       // chunk, first slot of the batch, end of the chunk (workgroup-uniform per wave: scalar registers)
-template <int NW, class Head, class Finish>
-__device__ __forceinline__ void ell_stream_w(const int nchunks, const int *co, const double *__restrict__ val, const int *__restrict__ idx, const double *in,
-                                             const int wid, const int lane, Head &&head, Finish &&finish) {
-  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-  auto issue = [&](EllBatch &b, const EllPos &p, const bool first) {
-    const int rem = p.e - p.s;
-    const long base = (long)p.s * WAVE + lane;
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int o = max(min(u, rem - 1), 0) * WAVE;
-      b.v[u] = val[base + o]; b.ix[u] = idx[base + o];
-    }
-    if (first) b.hd = head(p.c);
-  };
-  auto next_of = [&](const EllPos &p) {
-    EllPos q = p;
-    q.s += 8;
-    if (q.s >= q.e) {
-      q.c += NW;
-      if (q.c < nchunks) { q.s = rfl(co[q.c]); q.e = rfl(co[q.c + 1]); }
-    }
-    return q;
-  };
-  double acc = 0.0;
-  auto consume = [&](const EllBatch &b, const EllPos &p) {
-    const int rem = p.e - p.s;
-    double x[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) x[u] = in[b.ix[u]];
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < 8; u++) acc = __builtin_fma(u < rem ? b.v[u] : 0.0, x[u], acc);
-    if (p.s + 8 >= p.e) { finish(p.c, acc, b.hd); acc = 0.0; }
-  };
-  EllPos p0; p0.c = wid;
-  if (p0.c >= nchunks) return;
-  p0.s = rfl(co[p0.c]); p0.e = rfl(co[p0.c + 1]);
-  EllBatch A, B;
-  A.hd = d2v{0, 0}; B.hd = d2v{0, 0};
-  issue(A, p0, true);
-  for (;;) {
-    const EllPos p1 = next_of(p0);
-    const bool more1 = p1.c < nchunks;
-    if (more1) { B.hd = A.hd; issue(B, p1, p1.c != p0.c); }      // (a batch of the same chunk carries the chunk's head value along)
-    __builtin_amdgcn_sched_barrier(0);
-    consume(A, p0);
-    if (!more1) break;
-    p0 = next_of(p1);
-    const bool more0 = p0.c < nchunks;
-    if (more0) { A.hd = B.hd; issue(A, p0, p0.c != p1.c); }
-    __builtin_amdgcn_sched_barrier(0);
-    consume(B, p1);
-    if (!more0) break;
-  }
 }
 
 // The re-factorisation of an adaptive-rho step, OUT OF LINE.  Inlined into the iteration kernel (as the single kernel has it) its register pressure
@@ -441,6 +388,11 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
     if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
     else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
   };
+  const int myAt = oc_my_chunks<NW>(pl.At.chunk_off, pl.At.nchunks, wid, lane), myA = oc_my_chunks<NW>(pl.A.chunk_off, pl.A.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
+  // rho_i and 1 / rho_i of a row are selected from the three values the rho rule can produce (no per-row division); they change with rho only
+  double rho_in = 0, rho_eq = 0, ri_eq = 0, ri_in = 0; const double ri_min = 1.0 / Q_RHO_MIN;
+  auto rho_constants = [&]() { rho_in = opaque_uni(cx.rho); rho_eq = opaque_uni(Q_RHO_EQ * cx.rho); ri_eq = opaque_uni(1.0 / (Q_RHO_EQ * cx.rho)); ri_in = opaque_uni(1.0 / cx.rho); };
+  rho_constants();
   if (ok) {
     int iter;
     for (iter = iter0 + 1; iter <= st.max_iter; iter++) {
@@ -474,14 +426,13 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
         if (wid == 0) { ts_acc[9] += q1 - q0; ts_acc[10] += q2 - q1; ts_acc[11] += q3 - q2; ts_acc[12] += q4 - q3; }
         if (wid == NW - 1) { cx.fts[2] += q2 - q0; cx.fts[3] += q4 - q2; }
       }
-#elif defined(MPCQP_STREAM_SWEEP)
-      ell_stream_w<NW>(pl.At.nchunks, cx.coAt, valAt, pl.At.idx, cx.W, wid, lane, [&](const int) { return d2v{0, 0}; },
-                       [&](const int ch, const double v, const d2v) { const int t = ch * WAVE + lane; if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v; });
 #else
       for (int ch = wid; ch < pl.At.nchunks; ch += NW) {
         const int t = ch * WAVE + lane;
-        const double v = ell_chunk_g<OCU>(valAt, pl.At.idx, cx.W, cx.coAt[ch], cx.coAt[ch + 1], lane);
-        if (t < npad) cx.R[t] = sigma * cx.X[t] - cx.Q[t] + v;
+        const int k = (ch - wid) / NW;
+        const double xt = t < npad ? cx.X[t] : 0.0, qt = t < npad ? cx.Q[t] : 0.0;      // (read while the loads fly)
+        const double v = ell_chunk_g<OCU>(valAt, pl.At.idx, cx.W, __builtin_amdgcn_readlane(myAt, 2 * k), __builtin_amdgcn_readlane(myAt, 2 * k + 1), lane);
+        if (t < npad) cx.R[t] = v + __builtin_fma(sigma, xt, -qt);      // (written out: which products the compiler fuses in a * b - c + d depends on the order it meets them in)
       }
 #endif
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
@@ -499,40 +450,31 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
       const int do_rho = st.adaptive_rho && interval && (iter % interval == 0);
       const int save = can_check || do_rho;
       {
-        // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.  l, u are fetched before the row sum is
-        // accumulated; rho_i and 1 / rho_i are selected from the three values the rho rule can produce (no per-row division).
-        const double rho_eq = uni(Q_RHO_EQ * cx.rho), ri_min = 1.0 / Q_RHO_MIN, ri_eq = uni(1.0 / rho_eq), ri_in = uni(1.0 / cx.rho);
-#ifdef MPCQP_STREAM_SWEEP
-        ell_stream_w<NW>(pl.A.nchunks, cx.coA, valA, pl.A.idx, cx.R, wid, lane, [&](const int ch) { const int i = ch * WAVE + lane; return d2v{lb[i], ub[i]}; },
-                         [&](const int ch, const double zt, const d2v lu) {
-          const int i = ch * WAVE + lane;
-          const double lo = lu[0], up = lu[1];
-#else
+        // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.  l, u, z, y of the row are fetched before
+        // the row sum is accumulated.
         for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
-          const int i = ch * WAVE + lane;
+          const int i = ch * WAVE + lane, k = (ch - wid) / NW;
           const double lo = lb[i], up = ub[i];
-          const double zt = ell_chunk_g<OCU>(valA, pl.A.idx, cx.R, cx.coA[ch], cx.coA[ch + 1], lane);
-#endif
+          const double zo = i < mpad ? cx.Z[i] : 0.0, yo = i < mpad ? cx.Y[i] : 0.0;
+          const double zt = ell_chunk_g<OCU>(valA, pl.A.idx, cx.R, __builtin_amdgcn_readlane(myA, 2 * k), __builtin_amdgcn_readlane(myA, 2 * k + 1), lane);
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
-            const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : cx.rho), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
-            const double zr = alpha * zt + (1.0 - alpha) * cx.Z[i], yo = cx.Y[i];
-            const double zn = fmin(fmax(zr + rinv * yo, lo), up);
-            const double dy = rh * (zr - zn), yn = yo + dy;
-            cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = rh * zn - yn;
+            const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : rho_in), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);
+            // (every fused multiply-add written out, in the form the single kernel's build has: a * b + c * d may be contracted either way round)
+            const double zr = __builtin_fma(alpha, zt, (1.0 - alpha) * zo);
+            const double zn = fmin(fmax(__builtin_fma(rinv, yo, zr), lo), up);
+            const double dz = zr - zn, yn = __builtin_fma(rh, dz, yo);
+            cx.Z[i] = zn; cx.Y[i] = yn; cx.W[i] = __builtin_fma(rh, zn, -yn);
+            const double dy = rh * dz;
             if (save) dyg[i] = dy;
           }
-#ifdef MPCQP_STREAM_SWEEP
-        });
-#else
         }
-#endif
       }
       bsync<NW>();     // every wave has finished reading xtilde (R) as the gather source before X/R move on
       if (__builtin_expect(save, 0)) {     // (its own loop: the address of dx stays out of the iteration's live set)
-        for (int t = tid; t < npad; t += NT) { const double xo = cx.X[t]; dxg[t] = (alpha * cx.R[t] + (1.0 - alpha) * xo) - xo; }
+        for (int t = tid; t < npad; t += NT) { const double xo = cx.X[t]; dxg[t] = __builtin_fma(alpha, cx.R[t], (1.0 - alpha) * xo) - xo; }
       }
-      for (int t = tid; t < npad; t += NT) cx.X[t] = alpha * cx.R[t] + (1.0 - alpha) * cx.X[t];
+      for (int t = tid; t < npad; t += NT) cx.X[t] = __builtin_fma(alpha, cx.R[t], (1.0 - alpha) * cx.X[t]);
       bsync<NW>();
       TS(6);
       iter_done = iter;
@@ -566,6 +508,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
             if (!factorize_res<NW, (HUB ? 2 : 1)>(cx, &oc, octab, ocBL)) { status = MPCQP_NON_CVX; break; }
 #endif
             oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
+            rho_constants();
           }
         }
       }

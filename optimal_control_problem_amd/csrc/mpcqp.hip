@@ -401,7 +401,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
       // (single-kernel four-wave instance only: the eight-wave solve, oc_solve_long, has no ticket wait, and the two-kernel form sweeps all of A' up front)
-      h->split = !h->tiles && !getenv("MPCQP_OC_MONO");
+      h->split = !h->tiles && !getenv("MPCQP_OC_MONO") && pl.A.nchunks <= 32 * h->variant && pl.At.nchunks <= 32 * h->variant;      // (a wave's chunk offsets ride in the lanes of one register: kernel_oc_split.hpp oc_my_chunks)
       if (const char *e = getenv("MPCQP_RESUME_ROUNDS")) h->resume_rounds = std::max(0, std::min(atoi(e), 8));
       if (getenv("MPCQP_LATE") && !h->tiles && !h->oc8 && !h->split) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
