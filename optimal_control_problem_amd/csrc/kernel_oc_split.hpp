@@ -220,10 +220,26 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     // ---- load: caller's CSC values -> ELL arrays.  The block slots of LDS are idle until the factor comes on chip (in the other kernel), so the
     // ELL values of A (and P behind them) live there for the whole scaling phase when they fit (oc.a_lds / oc.p_lds, decided by the host) and
     // are written to the slab once, already scaled; A' is gathered from the caller's array when it is scaled.
+    // (the staged values through pointers whose memory the compiler KNOWS: `a_lds ? lds : valA` is a pointer to either, every access through it a
+    // flat load that takes both memory paths and waits for both counters -- the whole scaling phase ran on those; one copy of the phase per case)
     const bool a_lds = oc.a_lds, p_lds = oc.p_lds;
-    double *sA = a_lds ? lds : valA, *sP = p_lds ? lds + pl.A.entries : valP;
-    for (long e = tid; e < pl.A.entries; e += NT) { const int s = pl.A.src[e]; sA[e] = s >= 0 ? inA[s] : 0.0; }
-    for (long e = tid; e < pl.P.entries; e += NT) { const int s = pl.P.src[e]; sP[e] = s >= 0 ? inP[s] : 0.0; }
+    auto scale_phase = [&](double *sA, double *sP) __attribute__((always_inline)) {
+    // (eight source indices, then the eight values they point at, in flight at a time: one element per trip was two dependent round trips to memory each)
+    auto gather8 = [&](const int *__restrict__ src, const double *__restrict__ in, double *dst, const long entries) __attribute__((always_inline)) {
+      long e = tid;
+      for (; e + 7L * NT < entries; e += 8L * NT) {
+        int sr[8]; double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sr[u] = src[e + (long)u * NT];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = in[max(sr[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dst[e + (long)u * NT] = sr[u] >= 0 ? v[u] : 0.0;
+      }
+      for (; e < entries; e += NT) { const int sr = src[e]; dst[e] = sr >= 0 ? in[sr] : 0.0; }
+    };
+    gather8(pl.A.src, inA, sA, pl.A.entries);
+    gather8(pl.P.src, inP, sP, pl.P.entries);
     for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }
     for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
     bsync<NW>();
@@ -283,6 +299,10 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       lb[i] = i < m ? ei * fmax(inl[i], -Q_INFTY) : 0.0;
       ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
     }
+    };
+    if (a_lds && p_lds) scale_phase(lds, lds + pl.A.entries);
+    else if (a_lds) scale_phase(lds, valP);
+    else scale_phase(valA, valP);
   }
   for (int t = tid; t < npad; t += NT) Qs[t] = cx.Q[t];         // the scaled q crosses to the iteration kernel through the slab
   bsync<NW>();
@@ -438,7 +458,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
       bsync<NW>();
       TS(4);
-#if defined(MPCQP_TIMING) && !defined(MPCQP_TIMING_SWEEP)
+#if defined(MPCQP_TIMING) && !defined(MPCQP_TIMING_SWEEP) && !defined(MPCQP_TIMING_RUIZ)
       if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
       else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);
 #else
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
   bsync<NW>();
   ts_acc[13] = 0; ts_acc[14] = (unsigned long long)cx.RED[0]; ts_acc[15] = (unsigned long long)cx.RED[1];
   if (tid == 0 && io.dbg) for (int k_ = 9; k_ < 16; k_++) io.dbg[16L * b + k_] = 0;
-#elif defined(MPCQP_TIMING)
+#elif defined(MPCQP_TIMING) && !defined(MPCQP_TIMING_RUIZ)
   ts_acc[12] += cx.fts[0]; ts_acc[13] += cx.fts[1]; ts_acc[14] += cx.fts[2]; ts_acc[15] += cx.fts[3];
 #endif
   TS_STORE_ADD(io.dbg, 0, 16);

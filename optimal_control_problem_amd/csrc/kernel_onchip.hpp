@@ -248,33 +248,55 @@ __device__ __forceinline__ double oc_tiles_a(const DevTile &tl, const int rec, c
 template <int NW, int NG, int NH>
 __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, const double *slab, double *BL, const OcLane &ln, d4 (&G)[NG], d4 (&HF)[NH > 0 ? NH : 1],
                                                d4 (&HT)[NH > 0 ? NH : 1], const int wid, const int lane) {
-  for (int j = wid; j < oc.nlds; j += NW) {
-    const int src = oc_tab(tab, oc.o_fill + 3 * j), slot = oc_tab(tab, oc.o_fill + 3 * j + 1), neg = oc_tab(tab, oc.o_fill + 3 * j + 2);
-    d4 v = reinterpret_cast<const d4 *>(slab + (long)src * BLK)[lane];            // row lane >> 2, columns 4 (lane & 3) ...
-    if (neg) v = -v;
+  // This wave's table entries first, all of them, in the lanes of two registers (a table entry read where it is needed was a round trip to memory in
+  // front of every block's own round trip): lane 3 k + {0, 1, 2} = {source block, LDS slot, negate} of its k-th LDS block (the wave's blocks are
+  // j = wid + NW k; at most 21 of them: the host checks), lane 2 s + {0, 1} = {G block, hub block or -1} of its s-th position.
+  const int kf = lane / 3, jf = wid + NW * kf;
+  const int ftab = (kf < 21 && jf < oc.nlds) ? tab[oc.o_fill + 3 * jf + (lane - 3 * kf)] : 0;
+  const int ps = lane >> 1, pp = wid + NW * ps;
+  const int ptab = (ps < NG && pp < oc.nbc) ? tab[oc.o_pos + 5 * pp + 2 * (lane & 1)] : -1;
+  auto put = [&](const d4 v0, const int slot, const int neg) {
+    const d4 v = neg ? -v0 : v0;
     const int r = lane >> 2, c = 4 * (lane & 3);
     double *dst = BL + (long)slot * BLK;
     *reinterpret_cast<d2 *>(dst + oc_swz(r, c)) = d2{v[0], v[1]};
     *reinterpret_cast<d2 *>(dst + oc_swz(r, c + 2)) = d2{v[2], v[3]};
+  };
+  // four blocks in flight at a time (row lane >> 2, columns 4 (lane & 3) ...: one 32-byte load per lane and block)
+  int k = 0;
+  for (int j = wid; j < oc.nlds; j += 4 * NW, k += 4) {
+    d4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int src = __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20));
+      v[u] = reinterpret_cast<const d4 *>(slab + (long)src * BLK)[lane];         // (past the wave's last block: block 0 once more, dropped)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (j + u * NW < oc.nlds) put(v[u], __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 1), __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 2));
+  }
+  // register blocks: every load of the wave issued before the first use (operands of the 4-block MFMA: the block, resp. its transpose, as row
+  // lane & 15, columns (lane >> 4) + 4 K); a slot without a position reads block 0 and is zeroed
+  const int oA = (lane & 15) * BS + (lane >> 4), oD = (lane >> 4) * BS + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < NG; s++) {
+    const int gs = __builtin_amdgcn_readlane(ptab, 2 * s);
+    const double *gb = slab + (long)max(gs, 0) * BLK;
+    G[s] = d4{gb[oA], gb[oA + 4], gb[oA + 8], gb[oA + 12]};
+    if (s < NH) {
+      const int hs = __builtin_amdgcn_readlane(ptab, 2 * s + 1);
+      const double *hb = slab + (long)max(hs, 0) * BLK;
+      HF[s] = d4{hb[oA], hb[oA + 4], hb[oA + 8], hb[oA + 12]};
+      HT[s] = d4{hb[oD], hb[oD + 4 * BS], hb[oD + 8 * BS], hb[oD + 12 * BS]};
+    }
   }
 #pragma unroll
   for (int s = 0; s < NG; s++) {
-    const int p = wid + NW * s;
-    G[s] = d4{0, 0, 0, 0};
-    if (s < NH) { HF[s] = d4{0, 0, 0, 0}; HT[s] = d4{0, 0, 0, 0}; }
-    if (p < oc.nbc) {
-      const int gs = oc_tab(tab, oc.o_pos + 5 * p), hs = oc_tab(tab, oc.o_pos + 5 * p + 2);
-      // (operands of the 4-block MFMA: the block, resp. its transpose, as row lane & 15, columns (lane >> 4) + 4 K)
-      const int oA = (lane & 15) * BS + (lane >> 4), oD = (lane >> 4) * BS + (lane & 15);
-      const double *gb = slab + (long)gs * BLK;
-      G[s] = d4{gb[oA], gb[oA + 4], gb[oA + 8], gb[oA + 12]};
-      if (s < NH) {
-        if (hs >= 0) {
-          const double *hb = slab + (long)hs * BLK;
-          HF[s] = -d4{hb[oA], hb[oA + 4], hb[oA + 8], hb[oA + 12]};
-          HT[s] = -d4{hb[oD], hb[oD + 4 * BS], hb[oD + 8 * BS], hb[oD + 12 * BS]};
-        }
-      }
+    if (__builtin_amdgcn_readlane(ptab, 2 * s) < 0) G[s] = d4{0, 0, 0, 0};
+    if (s < NH) {
+      const bool has = __builtin_amdgcn_readlane(ptab, 2 * s + 1) >= 0;
+      HF[s] = has ? -HF[s] : d4{0, 0, 0, 0};
+      HT[s] = has ? -HT[s] : d4{0, 0, 0, 0};
     }
   }
   bsync<NW>();
