@@ -31,6 +31,7 @@ struct DevTile {
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
+  int nfill, o_s, o_dbl, ndbl, o_pp;   // LDS slots filled from the slab; the chains the solve walks; its double stages and their product blocks (plan.hpp oc_add_doubles)
   int at_poll, at_free;   // chunks of A' whose rows the iteration computes during the chain phase instead of before it (-1: none); see oc_solve
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
   const int *tab;
@@ -243,6 +244,42 @@ __device__ __forceinline__ double oc_tiles_a(const DevTile &tl, const int rec, c
   return e;
 }
 
+// ---- the hub and diagonal phases of the solve (F2, F3, B1) on the VECTOR ALUs.  They are wave-parallel products of independent blocks with
+// independent vectors, not dependent chains: what counts is throughput, and a 16 x 16 f64 mat-vec is four v_mfma_f64_4x4x4 = ~190 cycles of a
+// SIMD's matrix pipe (48 each, measured: tools/probes/chain_stage_probe.hip) against four v_fma_f64 and a quad sum = ~40 cycles of its vector
+// pipe.  (The chains stay on the matrix cores: there the point is latency -- no cross-lane reduction, the result already in operand layout.)
+// Row-piece layout: lane l = (r = l >> 2, j = l & 3) holds the four consecutive entries [r][4 j .. 4 j + 3] of a block and multiplies them with
+// the piece v[4 j .. 4 j + 3] of the vector (one 32-byte LDS read); the four lanes of a quad then hold the four partial sums of row r.
+__device__ __forceinline__ double oc_quad_sum(double v) {       // sum over the 4 lanes of a quad with DPP quad_perm (no LDS crossbar round trip)
+  union { double d; int i[2]; } a, t;
+  a.d = v;
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xF, 0xF, true);
+  a.d += t.d;
+  t.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+  t.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x4E, 0xF, 0xF, true);
+  return a.d + t.d;
+}
+__device__ __forceinline__ d4 oc_ldV4(const double *vec, const int p, const int lane) { return *reinterpret_cast<const d4 *>(vec + BS * p + 4 * (lane & 3)); }
+__device__ __forceinline__ void oc_stV(double *vec, const int p, const int lane, const double v) { vec[BS * p + (lane >> 2)] = v; }      // (the four lanes of a quad store the same value)
+__device__ __forceinline__ double oc_dot4(const d4 a, const d4 v, double acc) {
+  acc = __builtin_fma(a[0], v[0], acc); acc = __builtin_fma(a[1], v[1], acc); acc = __builtin_fma(a[2], v[2], acc); acc = __builtin_fma(a[3], v[3], acc);
+  return acc;
+}
+// row piece [r][4 j ..] of a block in its swizzled LDS image (oc_swz: the piece is one aligned group of four, its halves swapped in the lower rows)
+__device__ __forceinline__ d4 oc_ldsRow(const double *blk, const int lane) {
+  const int r = lane >> 2, j = lane & 3;
+  const d4 q = *reinterpret_cast<const d4 *>(blk + (((r ^ ((r >> 2) & 1)) << 4) | ((j ^ ((r >> 1) & 3)) << 2)));
+  return ((r >> 3) & 1) ? d4{q[2], q[3], q[0], q[1]} : q;
+}
+// ... and of its transpose: [4 j + i][c], c = lane >> 2
+__device__ __forceinline__ d4 oc_ldsRowT(const double *blk, const int lane) {
+  const int c = lane >> 2, j = 4 * (lane & 3);
+  return d4{blk[oc_swz(j, c)], blk[oc_swz(j + 1, c)], blk[oc_swz(j + 2, c)], blk[oc_swz(j + 3, c)]};
+}
+__device__ __forceinline__ d4 oc_ldD(const double *blk, const int lane);
+__device__ __forceinline__ d4 oc_ldA(const double *blk, const int lane);
+__device__ __forceinline__ d4 oc_mm(const d4 a, const d4 b, d4 acc);
 // After a factorisation (or on a kept workspace): bring the factor from the slab on chip.  Off-diagonal blocks are stored
 // negated, so that every op of the sweeps is an accumulation  acc += block * v.
 template <int NW, int NG, int NH>
@@ -252,7 +289,7 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
   // front of every block's own round trip): lane 3 k + {0, 1, 2} = {source block, LDS slot, negate} of its k-th LDS block (the wave's blocks are
   // j = wid + NW k; at most 21 of them: the host checks), lane 2 s + {0, 1} = {G block, hub block or -1} of its s-th position.
   const int kf = lane / 3, jf = wid + NW * kf;
-  const int ftab = (kf < 21 && jf < oc.nlds) ? tab[oc.o_fill + 3 * jf + (lane - 3 * kf)] : 0;
+  const int ftab = (kf < 21 && jf < oc.nfill) ? tab[oc.o_fill + 3 * jf + (lane - 3 * kf)] : 0;
   const int ps = lane >> 1, pp = wid + NW * ps;
   const int ptab = (ps < NG && pp < oc.nbc) ? tab[oc.o_pos + 5 * pp + 2 * (lane & 1)] : -1;
   auto put = [&](const d4 v0, const int slot, const int neg) {
@@ -264,7 +301,7 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
   };
   // four blocks in flight at a time (row lane >> 2, columns 4 (lane & 3) ...: one 32-byte load per lane and block)
   int k = 0;
-  for (int j = wid; j < oc.nlds; j += 4 * NW, k += 4) {
+  for (int j = wid; j < oc.nfill; j += 4 * NW, k += 4) {
     d4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -273,21 +310,20 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (j + u * NW < oc.nlds) put(v[u], __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 1), __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 2));
+      if (j + u * NW < oc.nfill) put(v[u], __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 1), __builtin_amdgcn_readlane(ftab, 3 * min(k + u, 20) + 2));
   }
-  // register blocks: every load of the wave issued before the first use (operands of the 4-block MFMA: the block, resp. its transpose, as row
-  // lane & 15, columns (lane >> 4) + 4 K); a slot without a position reads block 0 and is zeroed
-  const int oA = (lane & 15) * BS + (lane >> 4), oD = (lane >> 4) * BS + (lane & 15);
+  // register blocks, in the row-piece layout of the hub / diagonal phases (lane l: row l >> 2, entries 4 (l & 3) ...: one 32-byte load per lane; the
+  // transposed hub block as four strided loads), every load of the wave issued before the first use; a slot without a position reads block 0 and is zeroed
+  const int tc = lane >> 2, tj = 4 * (lane & 3);
 #pragma unroll
   for (int s = 0; s < NG; s++) {
     const int gs = __builtin_amdgcn_readlane(ptab, 2 * s);
-    const double *gb = slab + (long)max(gs, 0) * BLK;
-    G[s] = d4{gb[oA], gb[oA + 4], gb[oA + 8], gb[oA + 12]};
+    G[s] = reinterpret_cast<const d4 *>(slab + (long)max(gs, 0) * BLK)[lane];
     if (s < NH) {
       const int hs = __builtin_amdgcn_readlane(ptab, 2 * s + 1);
       const double *hb = slab + (long)max(hs, 0) * BLK;
-      HF[s] = d4{hb[oA], hb[oA + 4], hb[oA + 8], hb[oA + 12]};
-      HT[s] = d4{hb[oD], hb[oD + 4 * BS], hb[oD + 8 * BS], hb[oD + 12 * BS]};
+      HF[s] = reinterpret_cast<const d4 *>(hb)[lane];
+      HT[s] = d4{hb[tj * BS + tc], hb[(tj + 1) * BS + tc], hb[(tj + 2) * BS + tc], hb[(tj + 3) * BS + tc]};
     }
   }
 #pragma unroll
@@ -298,6 +334,15 @@ __device__ __forceinline__ void oc_load_factor(const DevOc &oc, const int *tab, 
       HF[s] = has ? -HF[s] : d4{0, 0, 0, 0};
       HT[s] = has ? -HT[s] : d4{0, 0, 0, 0};
     }
+  }
+  // product blocks of the double stages: W_b,m W_m,a (= the product of the two negated blocks the sweeps use) on the matrix cores, into their LDS slots
+  for (int j = wid; j < oc.ndbl; j += NW) {
+    const int sm = oc_tab(tab, oc.o_pp + 3 * j), sa = oc_tab(tab, oc.o_pp + 3 * j + 1), slot = oc_tab(tab, oc.o_pp + 3 * j + 2);
+    const d4 pr = oc_mm(oc_ldA(slab + (long)sm * BLK, lane), oc_ldD(slab + (long)sa * BLK, lane), d4{0, 0, 0, 0});      // D layout: lane 16 kk + n holds X[kk + 4 g][n]
+    double *dst = BL + (long)slot * BLK;
+    const int n = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 4; g++) dst[oc_swz(kk + 4 * g, n)] = pr[g];
   }
   bsync<NW>();
 }
@@ -533,12 +578,84 @@ __device__ __forceinline__ void oc_touch_pinned(const void *base, const long byt
   }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
+// F2, F3 and B1 of the solve on the vector ALUs (layout and cost: above oc_quad_sum).  On entry the chains have run forward and the junction term is
+// folded in; on exit every position holds d_p = G_p t_p - W_hub,p' x_hub and a workgroup barrier is due.  Returns this lane's element of x_hub (row
+// lane >> 2), which the caller stores once every wave has read the hub's right-hand side.
+template <int NW, int NG, int NH, bool HUB>
+__device__ __forceinline__ double oc_hub_phases(const DevOc &oc, const double *BL, double *R, double *EXT, const int lane, const OcWave<NG> &ow, const d4 (&G)[NG],
+                                                const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid) {
+  const int H = oc.nbc;
+  d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand piece
+  double xhd = 0.0;           // ... and as its row's element
+  if (HUB) {
+    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions (two accumulators: a v_fma_f64 can issue every 4 cycles, its result takes 8)
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NG; s++) {
+      const d4 t = oc_ldV4(R, ow.vpos[s], lane);
+      const d4 a = s < NH ? HF[s < NH ? s : 0] : oc_ldsRow(BL + (long)ow.hslot[s] * BLK, lane);
+      if (s & 1) p1 = oc_dot4(a, t, p1); else p0 = oc_dot4(a, t, p0);
+    }
+    oc_stV(EXT, 1 + wid, lane, oc_quad_sum(p0 + p1));
+    bsync<NW>();
+    // ---- F3: t_hub, x_hub = G_hub t_hub on every wave (cheaper than a barrier); the result goes through LDS once to become an operand piece (every
+    // wave writes the same values to the junction block, which is free by now)
+    d4 th = oc_ldV4(R, H, lane);
+#pragma unroll
+    for (int w = 0; w < NW; w++) th += oc_ldV4(EXT, 1 + w, lane);
+    xhd = oc_quad_sum(oc_dot4(oc_ldsRow(BL + (long)oc.ghub_slot * BLK, lane), th, 0.0));
+    oc_stV(EXT, 0, lane, xhd);
+    xh = oc_ldV4(EXT, 0, lane);
+  }
+  // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
+#pragma unroll
+  for (int s = 0; s < NG; s++) {
+    const d4 t = oc_ldV4(R, ow.vpos[s], lane);
+    double acc = oc_dot4(G[s], t, 0.0);
+    if (HUB) acc = oc_dot4(s < NH ? HT[s < NH ? s : 0] : oc_ldsRowT(BL + (long)ow.hslot[s] * BLK, lane), xh, acc);
+    const double d = oc_quad_sum(acc);
+    if (ow.ok[s]) oc_stV(R, ow.vpos[s], lane, d);
+  }
+  return xhd;
+}
 // Late rows of the right-hand side: the chains need the last vector blocks last, and waves 2, 3 are idle while they run.  So the sweep
 // over A' before the solve leaves out the chunk of the last chain positions (oc.at_poll) and the chunk of the hub's rows (oc.at_free, read
 // only after the barrier behind the chains); `late(wid)` computes them here, on wave 3 / wave 2.  The chain waves wait for wave 3's rows
 // at a fixed place -- the top of trip OC_POLL_TRIP, before any fetch of such a row (the host checks that: plan.hpp oc_late_chunks) -- on a
 // ticket in LDS that wave 3 sets to the iteration number once its rows are written.
 constexpr int OC_POLL_TRIP = 3;
+// The four wave-parallel phases around the chains of a solve with double stages (plan.hpp oc_add_doubles; double stage j = {a, m, b, slot of W_m,a,
+// slot of W_b,m}; all blocks negated: every op an accumulation):
+//   MODE 0, before the forward chains:   r_b += W_b,m r_m          (the bracket of  t_b = (r_b - W r_m) + (W W) t_a)
+//   MODE 1, behind them:                 t_m  = r_m + W_m,a t_a     (the position the double stage jumped over)
+//   MODE 2, before the backward chains:  d_a += W_m,a' d_m
+//   MODE 3, behind them:                 x_m  = d_m + W_b,m' x_b
+// Double stage j goes to wave j mod NW, up to three of a wave's interleaved (independent products hide the MFMA's 52-cycle dependency).  No two
+// stages touch the same destination, and a destination of one is never the source of another within a phase.
+template <int NW, int MODE>
+__device__ __forceinline__ void oc_double_phase(const DevOc &oc, const int *tab, const double *BL, double *R, const OcLane &ln, const int wid) {
+  for (int j0 = wid; j0 < oc.ndbl; j0 += 3 * NW) {
+    d4 a[3], v[3]; double acc[3]; int dst[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int j = min(j0 + u * NW, oc.ndbl - 1);
+      const int4 e = *reinterpret_cast<const int4 *>(tab + oc.o_dbl + 8 * j);      // {a, m, b, slot of W_m,a}; stays in vector registers: it only feeds LDS addresses
+      const int sm = tab[oc.o_dbl + 8 * j + 4];
+      const int src = MODE == 0 ? e.y : MODE == 1 ? e.x : MODE == 2 ? e.y : e.z;
+      dst[u] = MODE == 0 ? e.z : MODE == 1 ? e.y : MODE == 2 ? e.x : e.y;
+      const double *blk = BL + (long)((MODE == 0 || MODE == 3) ? sm : e.w) * BLK;
+      a[u] = MODE < 2 ? oc_ldF4(blk, ln) : oc_ldT4(blk, ln);
+      v[u] = d4{R[BS * src + ln.k4], R[BS * src + ln.k4 + 4], R[BS * src + ln.k4 + 8], R[BS * src + ln.k4 + 12]};
+      acc[u] = R[BS * dst[u] + ln.o4];
+    }
+#pragma unroll
+    for (int K = 0; K < 4; K++)
+#pragma unroll
+      for (int u = 0; u < 3; u++) acc[u] = oc_mv4(a[u][K], v[u][K], acc[u]);
+#pragma unroll
+    for (int u = 0; u < 3; u++) if (j0 + u * NW < oc.ndbl) R[BS * dst[u] + ln.o4] = acc[u];
+  }
+}
 // (Two texts of the same solve.  oc_solve is the four-wave form exactly as it was tuned in round 2 -- chain loops unrolled for OC_MAXT trips, two
 // position groups -- and oc_solve_long, further down, the form for the eight-wave instances: chain loops of any length, any number of position
 // groups, per-solve recomputation of the LDS addresses.  The product of merging them ran 5 % slower on the north-star size: this kernel's
@@ -554,10 +671,12 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
 #define OC_TS(k) __builtin_amdgcn_sched_barrier(0)
 #endif
   double *EXT = R + npad;                          // vector blocks behind the solve vector
-  const int LE = oc_tab(tab, 0), LF = oc_tab(tab, 1);
-  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_chainE : oc.o_chainF;
-  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_chainF + 2 * (LF - 1)) : -1;
+  // (the chains the SOLVE walks: with double stages they visit every other position; plan.hpp oc_add_doubles)
+  const int LE = oc_tab(tab, oc.o_s), LF = oc_tab(tab, oc.o_s + 1);
+  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_s + 2 : oc.o_s + 2 + 2 * LE;
+  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_s + 2 + 2 * LE + 2 * (LF - 1)) : -1;
   const int H = oc.nbc;
+  if (oc.ndbl) { oc_double_phase<NW, 0>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   // ---- F1
   // Two stages per trip with the roles of the two vector register sets swapped (x -> y -> x): no copy sits between an MFMA result
   // and the MFMAs that read it as their B operand.  The next stage's block and right-hand side are loaded while a stage multiplies;
@@ -609,96 +728,16 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     }
   }
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 1>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   OC_TS(0);
   if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
-  d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand pieces (k4 + 4 K)
-  double xhd = 0.0;           // ... and as its element of the result (o4)
-  constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
-  if (HUB) {
-    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions
-    double hsum = 0.0;
-    {
-      d4 t[NA], a[NA]; double acc[NA];
-#pragma unroll
-      for (int s = 0; s < NA; s++) { t[s] = oc_ldB4(R, ow.vpos[s], ln); a[s] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s] = 0.0; }
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(a[s][K], t[s][K], acc[s]);
-#pragma unroll
-      for (int s = 0; s < NA; s++) hsum += acc[s];
-    }
-    if (NG > NA) {
-      d4 t[NG - NA > 0 ? NG - NA : 1], a[NG - NA > 0 ? NG - NA : 1]; double acc[NG - NA > 0 ? NG - NA : 1];
-#pragma unroll
-      for (int s = NA; s < NG; s++) { t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); a[s - NA] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s] * BLK, ln); acc[s - NA] = 0.0; }
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(a[s - NA][K], t[s - NA][K], acc[s - NA]);
-#pragma unroll
-      for (int s = NA; s < NG; s++) hsum += acc[s - NA];
-    }
-    oc_stB4(EXT, 1 + wid, ln, hsum);
-    bsync<NW>();
-    // ---- F3: t_hub, x_hub = G_hub t_hub on every wave; the result goes through LDS once to become an operand (every wave writes the same
-    // values to the junction block, which is free by now)
-    d4 th = oc_ldB4(R, H, ln);
-#pragma unroll
-    for (int w = 0; w < NW; w++) th += oc_ldB4(EXT, 1 + w, ln);
-    const d4 gh = oc_ldF4(BL + (long)oc.ghub_slot * BLK, ln);
-#pragma unroll
-    for (int K = 0; K < 4; K++) xhd = oc_mv4(gh[K], th[K], xhd);
-    oc_stB4(EXT, 0, ln, xhd);
-    xh = oc_ldB4(EXT, 0, ln);
-  }
+  const double xhd = oc_hub_phases<NW, NG, NH, HUB>(oc, BL, R, EXT, threadIdx.x & 63, ow, G, HF, HT, wid);
   OC_TS(1);
-  // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
-  {
-    d4 t[NA], g[NA], h[NA]; double acc[NA];
-#pragma unroll
-    for (int s = 0; s < NA; s++) {
-      t[s] = oc_ldB4(R, ow.vpos[s], ln); g[s] = G[s]; acc[s] = 0.0;
-      if (HUB) h[s] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
-    }
-#pragma unroll
-    for (int K = 0; K < 4; K++)
-#pragma unroll
-      for (int s = 0; s < NA; s++) acc[s] = oc_mv4(g[s][K], t[s][K], acc[s]);
-    if (HUB) {
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = 0; s < NA; s++) acc[s] = oc_mv4(h[s][K], xh[K], acc[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < NA; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s]);
-  }
-  if (NG > NA) {
-    constexpr int NB = NG - NA > 0 ? NG - NA : 1;
-    d4 t[NB], g[NB], h[NB]; double acc[NB];
-#pragma unroll
-    for (int s = NA; s < NG; s++) {
-      t[s - NA] = oc_ldB4(R, ow.vpos[s], ln); g[s - NA] = G[s]; acc[s - NA] = 0.0;
-      if (HUB) h[s - NA] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s] * BLK, ln);
-    }
-#pragma unroll
-    for (int K = 0; K < 4; K++)
-#pragma unroll
-      for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(g[s - NA][K], t[s - NA][K], acc[s - NA]);
-    if (HUB) {
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int s = NA; s < NG; s++) acc[s - NA] = oc_mv4(h[s - NA][K], xh[K], acc[s - NA]);
-    }
-#pragma unroll
-    for (int s = NA; s < NG; s++) if (ow.ok[s]) oc_stB4(R, ow.vpos[s], ln, acc[s - NA]);
-  }
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 2>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   OC_TS(2);
   // ---- B2
-  if (HUB && wid == NW - 1) oc_stB4(R, H, ln, xhd);     // only now: every wave has read the hub's right-hand side
+  if (HUB && wid == NW - 1) oc_stV(R, H, threadIdx.x & 63, xhd);     // only now: every wave has read the hub's right-hand side
   if (wid < 2 && len > 0) {
     // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;
@@ -731,6 +770,7 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
     }
   } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
 #undef OC_TS
 }
 template <int NW, int NG, int NH, bool HUB, class Late, class Idle>
@@ -752,10 +792,12 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
 #define OC_TS(k) __builtin_amdgcn_sched_barrier(0)
 #endif
   double *EXT = R + npad;                          // vector blocks behind the solve vector
-  const int LE = oc_tab(tab, 0), LF = oc_tab(tab, 1);
-  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_chainE : oc.o_chainF;
-  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_chainF + 2 * (LF - 1)) : -1;
+  // (the chains the SOLVE walks: with double stages they visit every other position; plan.hpp oc_add_doubles)
+  const int LE = oc_tab(tab, oc.o_s), LF = oc_tab(tab, oc.o_s + 1);
+  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_s + 2 : oc.o_s + 2 + 2 * LE;
+  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_s + 2 + 2 * LE + 2 * (LF - 1)) : -1;
   const int H = oc.nbc;
+  if (oc.ndbl) { oc_double_phase<NW, 0>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   // ---- F1
   // Two stages per trip with the roles of the two vector register sets swapped (x -> y -> x): no copy sits between an MFMA result
   // and the MFMAs that read it as their B operand.  The next stage's block and right-hand side are loaded while a stage multiplies;
@@ -799,72 +841,16 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
     if (wid == 0 && oc.junc) oc_stB4(EXT, 0, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
   } else if (wid >= 2) late(wid);
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 1>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   OC_TS(0);
   if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
-  d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand pieces (k4 + 4 K)
-  double xhd = 0.0;           // ... and as its element of the result (o4)
-  constexpr int NA = NG < 3 ? NG : 3;          // positions multiplied together: slots [0, NA) and [NA, NG) (enough independent products to hide the 52-cycle dependency)
-  if (HUB) {
-    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions, NA of them multiplied together
-    double hsum = 0.0;
-#pragma unroll
-    for (int g0 = 0; g0 < NG; g0 += NA) {
-      d4 t[NA], a[NA]; double acc[NA];
-#pragma unroll
-      for (int u = 0; u < NA; u++) {
-        const int s = g0 + u;
-        if (s < NG) { t[u] = oc_ldB4(R, ow.vpos[s < NG ? s : 0], ln); a[u] = s < NH ? HF[s < NH ? s : 0] : oc_ldF4(BL + (long)ow.hslot[s < NG ? s : 0] * BLK, ln); acc[u] = 0.0; }
-      }
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(a[u][K], t[u][K], acc[u]);
-#pragma unroll
-      for (int u = 0; u < NA; u++) if (g0 + u < NG) hsum += acc[u];
-    }
-    oc_stB4(EXT, 1 + wid, ln, hsum);
-    bsync<NW>();
-    // ---- F3: t_hub, x_hub = G_hub t_hub on every wave; the result goes through LDS once to become an operand (every wave writes the same
-    // values to the junction block, which is free by now)
-    d4 th = oc_ldB4(R, H, ln);
-#pragma unroll
-    for (int w = 0; w < NW; w++) th += oc_ldB4(EXT, 1 + w, ln);
-    const d4 gh = oc_ldF4(BL + (long)oc.ghub_slot * BLK, ln);
-#pragma unroll
-    for (int K = 0; K < 4; K++) xhd = oc_mv4(gh[K], th[K], xhd);
-    oc_stB4(EXT, 0, ln, xhd);
-    xh = oc_ldB4(EXT, 0, ln);
-  }
+  const double xhd = oc_hub_phases<NW, NG, NH, HUB>(oc, BL, R, EXT, threadIdx.x & 63, ow, G, HF, HT, wid);
   OC_TS(1);
-  // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
-#pragma unroll
-  for (int g0 = 0; g0 < NG; g0 += NA) {
-    d4 t[NA], g[NA], h[NA]; double acc[NA];
-#pragma unroll
-    for (int u = 0; u < NA; u++) {
-      const int s = g0 + u;
-      if (s < NG) {
-        t[u] = oc_ldB4(R, ow.vpos[s < NG ? s : 0], ln); g[u] = G[s < NG ? s : 0]; acc[u] = 0.0;
-        if (HUB) h[u] = s < NH ? HT[s < NH ? s : 0] : oc_ldT4(BL + (long)ow.hslot[s < NG ? s : 0] * BLK, ln);
-      }
-    }
-#pragma unroll
-    for (int K = 0; K < 4; K++)
-#pragma unroll
-      for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(g[u][K], t[u][K], acc[u]);
-    if (HUB) {
-#pragma unroll
-      for (int K = 0; K < 4; K++)
-#pragma unroll
-        for (int u = 0; u < NA; u++) if (g0 + u < NG) acc[u] = oc_mv4(h[u][K], xh[K], acc[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < NA; u++) if (g0 + u < NG) { if (ow.ok[g0 + u < NG ? g0 + u : 0]) oc_stB4(R, ow.vpos[g0 + u < NG ? g0 + u : 0], ln, acc[u]); }
-  }
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 2>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   OC_TS(2);
   // ---- B2
-  if (HUB && wid == NW - 1) oc_stB4(R, H, ln, xhd);     // only now: every wave has read the hub's right-hand side
+  if (HUB && wid == NW - 1) oc_stV(R, H, threadIdx.x & 63, xhd);     // only now: every wave has read the hub's right-hand side
   if (wid < 2 && len > 0) {
     // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;
@@ -897,5 +883,6 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
     }
   } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
 #undef OC_TS
 }

@@ -347,6 +347,20 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         if (h->tiles) h->wl = ws_layout(pl, &h->tplan);
       }
       long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg, h->tiles ? &h->tplan : nullptr) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
+      if (h->oc && !h->tiles && getenv("MPCQP_DOUBLES")) {
+        // EXPERIMENT, opt-in (MPCQP_DOUBLES=<n>): double stages of the solve (plan.hpp oc_add_doubles) where the CU's LDS has room for their product blocks
+        // beside the factor: every one takes a dependent 16 x 16 mat-vec off the critical path of both triangular sweeps.  Parity-green, but measured
+        // SLOWER (cart-pole N=100: 29.1 against 27.8 ms): the four wave-parallel phases it adds (two mat-vecs per double stage and direction, 48 cycles
+        // of matrix pipe per MFMA, four more barriers) cost more than the halved chains save.
+        const long cap = h->oc8 ? OC8_LDS_MAX : OC_LDS_MAX;
+        int nd = (int)std::max<long>(0, (cap - need) / (BLK * 8));
+        nd = std::min(nd, std::max(0, atoi(getenv("MPCQP_DOUBLES"))));
+        for (; nd > 0; nd--) {       // (the table grows with the stages: take as many as still fit)
+          OcPlan o2 = h->ocplan; oc_add_doubles(o2, nd);
+          const long n2 = lds_bytes_oc(pl, h->rplan, o2, h->oc8 && h->zyg, nullptr);
+          if (n2 <= cap) { h->ocplan = o2; need = n2; break; }
+        }
+      }
       if (h->gblocks && !h->oc && want == 4 && !getenv("MPCQP_NO_ZYG")) {     // (the two-wave global-block kernel has no such instance: forced on a long horizon it took this layout and returned garbage)
         // long horizons: with z and y in the slab one more workgroup fits per CU (2 -> 3 or 1 -> 2); measured on quadrotor N=50
         const long alt = lds_bytes_res_gb(pl, h->rplan, true);
@@ -398,6 +412,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = oc_rext(rp.nw); dr.nconst = 0; dr.n_seg = 0;
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
+      d.nfill = o.nfill; d.o_s = o.o_s; d.o_dbl = o.o_dbl; d.ndbl = (int)o.dbl.size(); d.o_pp = o.o_pp;
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
       // (single-kernel four-wave instance only: the eight-wave solve, oc_solve_long, has no ticket wait, and the two-kernel form sweeps all of A' up front)

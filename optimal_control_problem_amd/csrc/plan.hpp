@@ -804,10 +804,80 @@ struct OcPlan {
   // then per position {gsrc, csrc, hsrc, cslot, hslot}, then the LDS fill list {src, slot, negate} x nlds
   std::vector<int> tab;
   int o_chainE = 0, o_chainF = 0, o_pos = 0, o_fill = 0;
+  // Double stages of the solve (oc_add_doubles): where LDS has room, two consecutive chain stages  t_m = rhs_m - W_a t_a,  t_b = rhs_b - W_m t_m  become
+  // ONE dependent stage  t_b = (rhs_b - W_m rhs_m) + (W_m W_a) t_a  with the product block kept in LDS beside the factor; the bracket and t_m are
+  // independent mat-vecs that all waves share before and after the chain phase (the backward sweep likewise, with the same product block read
+  // transposed).  The chains the solve walks (schainE / schainF: the positions it visits) are half as long; the factorisation is untouched.
+  struct Dbl { int a, m, b, slot_a, slot_m, slot_pp, src_a, src_m; };
+  std::vector<Dbl> dbl;
+  std::vector<int> schainE, schainF, sslotE, sslotF;      // visited positions and the LDS slot of the block (factor or product) that leads to the next one
+  int nfill = 0;                                          // LDS slots filled from the slab (the product slots behind them are computed on chip)
+  int o_s = 0, o_dbl = 0, o_pp = 0;
 };
 inline int oc_rext(int nw) { return (nw + 2) * BS; }     // behind the solve vector: the junction term, one hub partial sum per wave, a zero block
 constexpr int OC_CHAIN_SHORT = 17;          // the four-wave instances unroll their chain loops for 16 stages (kernel_onchip.hpp OC_MAXT); the eight-wave ones loop
 
+// the flat table the kernels read: [0] LE [1] LF, the chains as {position, LDS slot of W_succ(p),p} pairs (8-byte aligned; what oc_ldl walks), at o_s
+// {sLE, sLF} and the chains the SOLVE walks (visited positions, slot of the block -- factor or product -- that leads to the next), at o_dbl the double
+// stages {a, m, b, slot of W_m,a .. , slot of W_b,m, 0, 0, 0} (8 ints each), then (o_pos) per position {gsrc, csrc, hsrc, cslot, hslot}, (o_fill) the
+// LDS fill list {src, slot, negate} x nfill, and (o_pp) per double stage {slab block of W_b,m, slab block of W_m,a, LDS slot of their product}
+inline void oc_build_tab(OcPlan &oc) {
+  const int nbc = oc.nbc;
+  if (oc.dbl.empty()) {
+    oc.schainE = oc.chainE; oc.schainF = oc.chainF;
+    oc.sslotE.clear(); oc.sslotF.clear();
+    for (int p : oc.chainE) oc.sslotE.push_back(std::max(oc.cslot[p], 0));
+    for (int p : oc.chainF) oc.sslotF.push_back(std::max(oc.cslot[p], 0));
+  }
+  oc.tab.clear();
+  oc.tab.push_back((int)oc.chainE.size()); oc.tab.push_back((int)oc.chainF.size());
+  // (a chain end without a block below it carries slot 0: the kernel's prefetch reads one stage past the end and drops the result)
+  oc.o_chainE = (int)oc.tab.size(); for (int p : oc.chainE) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
+  oc.o_chainF = (int)oc.tab.size(); for (int p : oc.chainF) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
+  oc.o_s = (int)oc.tab.size();
+  oc.tab.push_back((int)oc.schainE.size()); oc.tab.push_back((int)oc.schainF.size());
+  for (size_t k = 0; k < oc.schainE.size(); k++) { oc.tab.push_back(oc.schainE[k]); oc.tab.push_back(oc.sslotE[k]); }
+  for (size_t k = 0; k < oc.schainF.size(); k++) { oc.tab.push_back(oc.schainF[k]); oc.tab.push_back(oc.sslotF[k]); }
+  oc.o_dbl = (int)oc.tab.size();
+  for (const OcPlan::Dbl &d : oc.dbl) { int r[8] = {d.a, d.m, d.b, d.slot_a, d.slot_m, 0, 0, 0}; oc.tab.insert(oc.tab.end(), r, r + 8); }
+  oc.o_pos = (int)oc.tab.size();
+  for (int p = 0; p < nbc; p++) { int r[5] = {oc.gsrc[p], oc.csrc[p], oc.hsrc[p], oc.cslot[p], oc.hslot[p]}; oc.tab.insert(oc.tab.end(), r, r + 5); }
+  oc.o_fill = (int)oc.tab.size();
+  for (int p = 0; p < nbc; p++) if (oc.cslot[p] >= 0) { int r[3] = {oc.csrc[p], oc.cslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  if (oc.has_hub) { int r[3] = {oc.ghub_src, oc.ghub_slot, 0}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  for (int p = 0; p < nbc; p++) if (oc.hslot[p] >= 0) { int r[3] = {oc.hsrc[p], oc.hslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  oc.o_pp = (int)oc.tab.size();
+  for (const OcPlan::Dbl &d : oc.dbl) { int r[3] = {d.src_m, d.src_a, d.slot_pp}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+}
+// up to max_doubles double stages, handed out to whichever chain still has more dependent stages to walk; along a chain they are taken from its
+// head, pair after pair, and never jump over a chain's last position (the junction term and the junction itself need it as it is)
+inline void oc_add_doubles(OcPlan &oc, int max_doubles) {
+  oc.dbl.clear(); oc.nlds = oc.nfill;
+  if (!oc.ok || max_doubles <= 0) { oc_build_tab(oc); return; }
+  int nE = 0, nF = 0;                                   // doubles taken per chain
+  const int LE = (int)oc.chainE.size(), LF = (int)oc.chainF.size();
+  auto can = [](int L, int nd) { return 2 * (nd + 1) <= L - 1; };     // the (nd + 1)-th double ends at index 2 (nd + 1) <= L - 1
+  for (int k = 0; k < max_doubles; k++) {
+    const int remE = LE - nE, remF = LF - nF;           // positions still visited
+    const bool cE = can(LE, nE), cF = can(LF, nF);
+    if (!cE && !cF) break;
+    if (cE && (!cF || remE >= remF)) nE++; else nF++;
+  }
+  auto build = [&](const std::vector<int> &ch, int nd, std::vector<int> &vis, std::vector<int> &slot) {
+    vis.clear(); slot.clear();
+    size_t k = 0;
+    for (int d = 0; d < nd; d++, k += 2) {
+      OcPlan::Dbl e; e.a = ch[k]; e.m = ch[k + 1]; e.b = ch[k + 2]; e.slot_a = oc.cslot[e.a]; e.slot_m = oc.cslot[e.m]; e.src_a = oc.csrc[e.a]; e.src_m = oc.csrc[e.m];
+      e.slot_pp = oc.nlds++;
+      oc.dbl.push_back(e);
+      vis.push_back(e.a); slot.push_back(e.slot_pp);
+    }
+    for (; k < ch.size(); k++) { vis.push_back(ch[k]); slot.push_back(std::max(oc.cslot[ch[k]], 0)); }
+  };
+  build(oc.chainE, nE, oc.schainE, oc.sslotE);
+  build(oc.chainF, nF, oc.schainF, oc.sslotF);
+  oc_build_tab(oc);
+}
 inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_npw, int max_nhr, int max_chain = OC_CHAIN_SHORT) {
   OcPlan oc;
   const int nb = pl.nb;
@@ -870,18 +940,9 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
   }
   if (slots > max_lds_blocks) return oc;
   oc.nlds = slots;
-  // device table
-  oc.tab.push_back((int)oc.chainE.size()); oc.tab.push_back((int)oc.chainF.size());
-  // (a chain end without a block below it carries slot 0: the kernel's prefetch reads one stage past the end and drops the result)
-  oc.o_chainE = (int)oc.tab.size(); for (int p : oc.chainE) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
-  oc.o_chainF = (int)oc.tab.size(); for (int p : oc.chainF) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
-  oc.o_pos = (int)oc.tab.size();
-  for (int p = 0; p < nbc; p++) { int r[5] = {oc.gsrc[p], oc.csrc[p], oc.hsrc[p], oc.cslot[p], oc.hslot[p]}; oc.tab.insert(oc.tab.end(), r, r + 5); }
-  oc.o_fill = (int)oc.tab.size();
-  for (int p = 0; p < nbc; p++) if (oc.cslot[p] >= 0) { int r[3] = {oc.csrc[p], oc.cslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
-  if (oc.has_hub) { int r[3] = {oc.ghub_src, oc.ghub_slot, 0}; oc.tab.insert(oc.tab.end(), r, r + 3); }
-  for (int p = 0; p < nbc; p++) if (oc.hslot[p] >= 0) { int r[3] = {oc.hsrc[p], oc.hslot[p], 1}; oc.tab.insert(oc.tab.end(), r, r + 3); }
+  oc.nfill = oc.nlds;
   oc.ok = true;
+  oc_build_tab(oc);
   return oc;
 }
 // LDS of the on-chip variant: block slots (the factorisation's temp tiles and the staged ELL values alias them), x, q, r (+ the
