@@ -83,42 +83,6 @@ __device__ __forceinline__ double opaque_uni(const double v) {
   lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// ell_chunk with the gathers of a batch issued TOGETHER.  In ell_batch the compiler serialises "x = in[idx]; acc += v * x" slot by slot: wait for the
-// index, compute the LDS address, ds_read, wait for it (lgkmcnt(0)), fma -- one exposed LDS round trip of ~100 cycles per slot, 1,500 cycles for a
-// batch of 16 (measured with the MPCQP_TIMING_SWEEP build: issue of the 32 loads 1,512 cycles, wait for them 858, gathers + fma 1,552).  Here all U
-// LDS reads of a batch are in flight before the first fma (a compiler barrier between the two loops); the sum is still accumulated slot by slot in
-// ascending order with one fma each: the same bits.
-template <int U>
-__device__ __forceinline__ double ell_batch_g(const double *__restrict__ &vp, const int *__restrict__ &ip, const double *in, double acc) {
-  double v[U], x[U]; int ix[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
-#pragma unroll
-  for (int u = 0; u < U; u++) x[u] = in[ix[u]];
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int u = 0; u < U; u++) acc = __builtin_fma(v[u], x[u], acc);
-  vp += U * WAVE; ip += U * WAVE;
-  return acc;
-}
-template <int UMAX>
-__device__ __forceinline__ double ell_chunk_g(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
-  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
-  const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
-  double acc = 0.0;
-  int rem = s1 - s0;
-  if (UMAX >= 16) {
-    for (; rem >= 16; rem -= 16) acc = ell_batch_g<16>(vp, ip, in, acc);
-    if (rem & 8) acc = ell_batch_g<8>(vp, ip, in, acc);
-  } else {
-    for (; rem >= 8; rem -= 8) acc = ell_batch_g<8>(vp, ip, in, acc);
-  }
-  if (rem & 4) acc = ell_batch_g<4>(vp, ip, in, acc);
-  if (rem & 2) acc = ell_batch_g<2>(vp, ip, in, acc);
-  if (rem & 1) acc = ell_batch_g<1>(vp, ip, in, acc);
-  return acc;
-}
-
 // The re-factorisation of an adaptive-rho step, OUT OF LINE.  Inlined into the iteration kernel (as the single kernel has it) its register pressure
 // -- twelve operand tiles of the assembly, nine carried blocks of oc_ldl -- was behind 600 - 900 of that kernel's 700 - 1,100 spilled VGPRs although
 // it runs once in a hundred iterations, if at all.  As a function of its own it has its own allocation; the caller's resident blocks are dead across
@@ -459,11 +423,15 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
       bsync<NW>();
       TS(4);
 #if defined(MPCQP_TIMING) && !defined(MPCQP_TIMING_SWEEP) && !defined(MPCQP_TIMING_RUIZ)
-      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
-      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, ts_acc + 9);
+      unsigned long long *const stamps = ts_acc + 9;   // slots 9..11: F1, F2 + F3 + B1, the barrier behind them (B2 = the rest of the solve)
 #else
-      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch);
-      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch);
+      unsigned long long *const stamps = nullptr;
+#endif
+#ifndef MPCQP_VALU_CHAINS     // (experiment, -DMPCQP_VALU_CHAINS: the chains on the vector ALUs too -- oc_solve_v: parity-green, 4 - 20 % slower)
+      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
+      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
+#else
+      oc_solve_v<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, idle_touch, stamps);
 #endif
       TS(5);
       can_check = st.check_termination && (iter % st.check_termination == 0);
@@ -499,13 +467,13 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
       TS(6);
       iter_done = iter;
       if (__builtin_expect(can_check, 0)) {     // (rare paths are marked cold: their register pressure must not cost the hot loop its registers)
-        update_info_res<NW>(cx, in);
+        update_info_res<NW, true>(cx, in);
         status = check_termination_res<NW>(cx, in, 0);
         TS(7);
         if (status != MPCQP_UNSOLVED) break;
       }
       if (__builtin_expect(do_rho, 0)) {
-        if (!can_check) update_info_res<NW>(cx, in);
+        if (!can_check) update_info_res<NW, true>(cx, in);
         const double pr = in.prs / (fmax(in.nzs, in.naxs) + Q_DIV_TOL);
         const double dr = in.drs / (fmax(in.nqs, fmax(in.natys, in.npxs)) + Q_DIV_TOL);
         double rn = cx.rho * sqrt(pr / (dr + Q_DIV_TOL));
@@ -535,7 +503,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
     }
     if (iter > st.max_iter) iter_done = st.max_iter;
     if (status == MPCQP_UNSOLVED) {
-      if (!can_check) { update_info_res<NW>(cx, in); status = check_termination_res<NW>(cx, in, 0); }
+      if (!can_check) { update_info_res<NW, true>(cx, in); status = check_termination_res<NW>(cx, in, 0); }
       if (status == MPCQP_UNSOLVED) { status = check_termination_res<NW>(cx, in, 1); if (status == MPCQP_UNSOLVED) status = MPCQP_MAX_ITER_REACHED; }
     }
   }

@@ -587,15 +587,22 @@ __device__ __forceinline__ double oc_hub_phases(const DevOc &oc, const double *B
   const int H = oc.nbc;
   d4 xh = {0, 0, 0, 0};       // x_hub as this lane's operand piece
   double xhd = 0.0;           // ... and as its row's element
-  if (HUB) {
-    // ---- F2: partial sums  -sum W_hub,p t_p  over this wave's positions (two accumulators: a v_fma_f64 can issue every 4 cycles, its result takes 8)
-    double p0 = 0.0, p1 = 0.0;
+  // one pass over the wave's positions serves F2 (-sum W_hub,p t_p; two accumulators: a v_fma_f64 issues every 4 cycles, its result takes 8) and the
+  // part of B1 that does not wait for x_hub (G_p t_p): t_p is read once, and the products run in the shadow of the barrier
+  // (... where the instance has the registers for NG sums across the barrier: with seven positions per wave -- 168 resident VGPRs -- the fourteen
+  // more spilled into the iteration, 13.1 against 12.3 ms on quadrotor N=50 x 4096; there G_p t_p waits for B1)
+  constexpr bool EARLY = NG <= 5;
+  double p0 = 0.0, p1 = 0.0, acc[NG];
 #pragma unroll
-    for (int s = 0; s < NG; s++) {
-      const d4 t = oc_ldV4(R, ow.vpos[s], lane);
+  for (int s = 0; s < NG; s++) {
+    const d4 t = oc_ldV4(R, ow.vpos[s], lane);
+    if (HUB) {
       const d4 a = s < NH ? HF[s < NH ? s : 0] : oc_ldsRow(BL + (long)ow.hslot[s] * BLK, lane);
       if (s & 1) p1 = oc_dot4(a, t, p1); else p0 = oc_dot4(a, t, p0);
     }
+    if (EARLY) acc[s] = oc_dot4(G[s], t, 0.0);
+  }
+  if (HUB) {
     oc_stV(EXT, 1 + wid, lane, oc_quad_sum(p0 + p1));
     bsync<NW>();
     // ---- F3: t_hub, x_hub = G_hub t_hub on every wave (cheaper than a barrier); the result goes through LDS once to become an operand piece (every
@@ -610,10 +617,9 @@ __device__ __forceinline__ double oc_hub_phases(const DevOc &oc, const double *B
   // ---- B1: d_p = G_p t_p - W_hub,p' x_hub for this wave's positions
 #pragma unroll
   for (int s = 0; s < NG; s++) {
-    const d4 t = oc_ldV4(R, ow.vpos[s], lane);
-    double acc = oc_dot4(G[s], t, 0.0);
-    if (HUB) acc = oc_dot4(s < NH ? HT[s < NH ? s : 0] : oc_ldsRowT(BL + (long)ow.hslot[s] * BLK, lane), xh, acc);
-    const double d = oc_quad_sum(acc);
+    if (!EARLY) acc[s] = oc_dot4(G[s], oc_ldV4(R, ow.vpos[s], lane), 0.0);
+    if (HUB) acc[s] = oc_dot4(s < NH ? HT[s < NH ? s : 0] : oc_ldsRowT(BL + (long)ow.hslot[s] * BLK, lane), xh, acc[s]);
+    const double d = oc_quad_sum(acc[s]);
     if (ow.ok[s]) oc_stV(R, ow.vpos[s], lane, d);
   }
   return xhd;
@@ -882,6 +888,131 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
       if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
     }
   } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
+  bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
+#undef OC_TS
+}
+
+// =========================================================================================================
+// The solve with its CHAINS on the vector ALUs as well (round 4).  A chain stage  t_next = rhs_next - W t  is a dependent 16 x 16 mat-vec.  On the
+// matrix cores it is four v_mfma_f64_4x4x4_4b_f64 behind each other, 52 cycles each (the f64 4-block MFMA occupies the matrix pipe for ~48 cycles
+// whether the next one depends on it or not), then eight ds_swizzle to turn the result into the next operand: 330 - 400 cycles in the kernels.  On the
+// vector ALUs, in the row-piece layout (lane l = (r = l >> 2, j = l & 3) holds W[r][4 j .. 4 j + 3]): four dependent v_fma_f64 (a wave64 f64 fma issues
+// in 4 cycles), a quad sum by DPP, and eight ds_bpermute that fetch the next operand piece x[4 j .. 4 j + 3] from the quads 4 j .. 4 j + 3 -- the same
+// trip through the LDS crossbar as the swizzles, behind ~90 cycles of arithmetic instead of ~210.  A block is read from its swizzled LDS image as one
+// 32-byte row piece (forward) or four 8-byte entries (backward); the right-hand side element joins the sum in the lane with j = 0.
+// Same phases, barriers and tables as oc_solve / oc_solve_long; chain loops of any length.
+// MEASURED SLOWER, not the default (build with -DMPCQP_VALU_CHAINS): quadrotor N=20 x 8192 iteration kernel 5.67 against 5.36 ms, N=50 x 4096 14.8 against
+// 12.3, cart-pole N=100 x 4096 26.8 against 25.8 -- the eight ds_bpermute (a full crossbar gather with an address register each) and the two dependent
+// DPP rounds of the quad sum cost more than the matrix pipe's 4 x 52 cycles save; the hub and diagonal phases, which have no hand-over, did gain.
+__device__ __forceinline__ double oc_bperm(const double v, const int byte_addr) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_ds_bpermute(byte_addr, a.i[0]); r.i[1] = __builtin_amdgcn_ds_bpermute(byte_addr, a.i[1]);
+  return r.d;
+}
+// the operand piece of the next stage from the row sums of this one: entry 4 j + i sits in (every lane of) quad 4 j + i = lanes 16 j + 4 i ...
+__device__ __forceinline__ d4 oc_next_piece(const double y, const int lane) {
+  const int b = 64 * (lane & 3);       // byte address of lane 16 j
+  return d4{oc_bperm(y, b), oc_bperm(y, b + 16), oc_bperm(y, b + 32), oc_bperm(y, b + 48)};
+}
+template <int NW, int NG, int NH, bool HUB, class Idle>
+__device__ __forceinline__ void oc_solve_v(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln, const OcWave<NG> &ow_,
+                                           const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid, Idle &&idle,
+                                           unsigned long long *stamp = nullptr) {
+  // (the LDS addresses of a wave's positions are recomputed per solve from opaque inputs: hoisted out of the ADMM loop they are spilled -- see oc_solve_long)
+  OcWave<NG> ow = ow_;
+#pragma unroll
+  for (int s = 0; s < NG; s++) asm volatile("" : "+s"(ow.vpos[s]), "+s"(ow.hslot[s]));
+#ifdef MPCQP_TIMING
+#define OC_TS(k) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[k] += t_ - t0_; t0_ = t_; } } while (0)
+  unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#else
+#define OC_TS(k) __builtin_amdgcn_sched_barrier(0)
+#endif
+  const int lane = threadIdx.x & 63;
+  const double jz = (lane & 3) == 0 ? 1.0 : 0.0;     // the right-hand side element joins the row sum in one lane of the quad
+  double *EXT = R + npad;                            // vector blocks behind the solve vector
+  const int LE = oc_tab(tab, oc.o_s), LF = oc_tab(tab, oc.o_s + 1);
+  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_s + 2 : oc.o_s + 2 + 2 * LE;
+  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_s + 2 + 2 * LE + 2 * (LF - 1)) : -1;
+  const int H = oc.nbc;
+  if (oc.ndbl) { oc_double_phase<NW, 0>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
+  // ---- F1: the chains, one wave each.  Two stages per trip with the roles of the two operand register sets swapped; the next stage's block, right-hand
+  // side element and table entries are fetched while a stage multiplies (table reads past the end are clamped to the last entry: no branch in a trip)
+  if (wid < 2 && len > 0) {
+    const int nst = len - 1;                           // stage k multiplies block e[k].y into position e[k + 1].x
+    int2 e0 = oc_pair(tab, cb), e1 = oc_pair(tab, cb + 2 * min(1, nst)), e2 = oc_pair(tab, cb + 2 * min(2, nst)), e3 = oc_pair(tab, cb + 2 * min(3, nst));
+    d4 x = oc_ldV4(R, e0.x, lane), y = x;
+    d4 a = oc_ldsRow(BL + (long)e0.y * BLK, lane); double c = R[BS * e1.x + (lane >> 2)];
+    int k = 0;
+    auto trip2 = [&]() {
+      const d4 a1 = oc_ldsRow(BL + (long)e1.y * BLK, lane); const double c1 = R[BS * e2.x + (lane >> 2)];
+      const int2 e4 = oc_pair(tab, cb + 2 * min(k + 4, nst)), e5 = oc_pair(tab, cb + 2 * min(k + 5, nst));
+      __builtin_amdgcn_sched_barrier(0);
+      const double r0 = oc_quad_sum(oc_dot4(a, x, jz * c));
+      y = oc_next_piece(r0, lane);                     // (the hand-over first: the LDS pipe is in order, and the next stage waits for exactly this)
+      __builtin_amdgcn_sched_barrier(0);
+      oc_stV(R, e1.x, lane, r0);
+      a = oc_ldsRow(BL + (long)e2.y * BLK, lane); c = R[BS * e3.x + (lane >> 2)];
+      __builtin_amdgcn_sched_barrier(0);
+      const double r1 = oc_quad_sum(oc_dot4(a1, y, jz * c1));
+      x = oc_next_piece(r1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      oc_stV(R, e2.x, lane, r1);
+      e0 = e2; e1 = e3; e2 = e4; e3 = e5; k += 2;
+    };
+#pragma unroll 1
+    while (k + 2 <= nst) trip2();
+    if (k < nst) {                                     // odd stage count: one more
+      const double r0 = oc_quad_sum(oc_dot4(a, x, jz * c));
+      oc_stV(R, e1.x, lane, r0);
+      x = oc_next_piece(r0, lane); e0 = e1;
+    }
+    // x = t of the chain's last position e0.x; the wave of chain E ends with the junction term
+    if (wid == 0 && oc.junc) oc_stV(EXT, 0, lane, oc_quad_sum(oc_dot4(oc_ldsRow(BL + (long)e0.y * BLK, lane), x, 0.0)));
+  }
+  bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 1>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
+  OC_TS(0);
+  if (f >= 0 && wid == (f & (NW - 1))) oc_stV(R, f, lane, R[BS * f + (lane >> 2)] + EXT[lane >> 2]);      // t_f complete (its owner reads it back in order)
+  const double xhd = oc_hub_phases<NW, NG, NH, HUB>(oc, BL, R, EXT, lane, ow, G, HF, HT, wid);
+  OC_TS(1);
+  bsync<NW>();
+  if (oc.ndbl) { oc_double_phase<NW, 2>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
+  OC_TS(2);
+  // ---- B2: the chains backwards: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
+  if (HUB && wid == NW - 1) oc_stV(R, H, lane, xhd);     // only now: every wave has read the hub's right-hand side
+  if (wid < 2 && len > 0) {
+    int k = len - 2;
+    d4 x;
+    if (wid == 0 && oc.junc) { x = oc_ldV4(R, f, lane); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
+    else x = oc_ldV4(R, tab[cb + 2 * (len - 1)], lane);
+    if (k >= 0) {
+      int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
+      d4 y = x;
+      d4 a = oc_ldsRowT(BL + (long)e0.y * BLK, lane); double c = R[BS * e0.x + (lane >> 2)];
+      auto trip2 = [&]() {
+        const d4 a1 = oc_ldsRowT(BL + (long)e1.y * BLK, lane); const double c1 = R[BS * e1.x + (lane >> 2)];
+        const int2 e4 = oc_pair(tab, cb + 2 * max(k - 4, 0)), e5 = oc_pair(tab, cb + 2 * max(k - 5, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        const double r0 = oc_quad_sum(oc_dot4(a, x, jz * c));
+        y = oc_next_piece(r0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stV(R, e0.x, lane, r0);
+        a = oc_ldsRowT(BL + (long)e2.y * BLK, lane); c = R[BS * e2.x + (lane >> 2)];
+        __builtin_amdgcn_sched_barrier(0);
+        const double r1 = oc_quad_sum(oc_dot4(a1, y, jz * c1));
+        x = oc_next_piece(r1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        oc_stV(R, e1.x, lane, r1);
+        e0 = e2; e1 = e3; e2 = e4; e3 = e5; k -= 2;
+      };
+#pragma unroll 1
+      while (k >= 1) trip2();
+      if (k == 0) oc_stV(R, e0.x, lane, oc_quad_sum(oc_dot4(a, x, jz * c)));
+    }
+  } else if (wid >= 2) idle(wid);       // (the other waves have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();
   if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
 #undef OC_TS

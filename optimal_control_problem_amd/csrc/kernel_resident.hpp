@@ -94,6 +94,42 @@ __device__ __forceinline__ double ell_chunk(const double *__restrict__ val, cons
   if (rem & 1) acc = ell_batch<MAXABS, 1>(vp, ip, in, acc);
   return acc;
 }
+// ell_chunk with the gathers of a batch issued TOGETHER.  In ell_batch the compiler serialises "x = in[idx]; acc += v * x" slot by slot: wait for the
+// index, compute the LDS address, ds_read, wait for it (lgkmcnt(0)), fma -- one exposed LDS round trip of ~100 cycles per slot, 1,500 cycles for a
+// batch of 16 (measured with the MPCQP_TIMING_SWEEP build: issue of the 32 loads 1,512 cycles, wait for them 858, gathers + fma 1,552).  Here all U
+// LDS reads of a batch are in flight before the first fma (a compiler barrier between the two loops); the sum is still accumulated slot by slot in
+// ascending order with one fma each: the same bits.
+template <int U>
+__device__ __forceinline__ double ell_batch_g(const double *__restrict__ &vp, const int *__restrict__ &ip, const double *in, double acc) {
+  double v[U], x[U]; int ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) x[u] = in[ix[u]];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < U; u++) acc = __builtin_fma(v[u], x[u], acc);
+  vp += U * WAVE; ip += U * WAVE;
+  return acc;
+}
+template <int UMAX>
+__device__ __forceinline__ double ell_chunk_g(const double *__restrict__ val, const int *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
+  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
+  const int *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
+  double acc = 0.0;
+  int rem = s1 - s0;
+  if (UMAX >= 16) {
+    for (; rem >= 16; rem -= 16) acc = ell_batch_g<16>(vp, ip, in, acc);
+    if (rem & 8) acc = ell_batch_g<8>(vp, ip, in, acc);
+  } else {
+    for (; rem >= 8; rem -= 8) acc = ell_batch_g<8>(vp, ip, in, acc);
+  }
+  if (rem & 4) acc = ell_batch_g<4>(vp, ip, in, acc);
+  if (rem & 2) acc = ell_batch_g<2>(vp, ip, in, acc);
+  if (rem & 1) acc = ell_batch_g<1>(vp, ip, in, acc);
+  return acc;
+}
+
 // Ruiz equilibration, one sweep over A by rows for both norms: max_j |a_ij| d_j stays in the row's lane, and |a_ij| e_i goes to column
 // j's accumulator with an LDS atomic max on the bit pattern (non-negative doubles order like their bit patterns) -- A' is not read.
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -567,7 +603,8 @@ __device__ __forceinline__ bool factorize_res(RCtx &cx, const DevOc *oc = nullpt
   return true;
 }
 
-template <int NW>
+// GATHERS: the sweeps through ell_chunk_g (the LDS gathers of a batch in flight together; the two-kernel on-chip mode)
+template <int NW, bool GATHERS = false>
 __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
   const DevPlan &pl = *cx.pl; double *ws = cx.ws; const int wid = cx.wid, lane = cx.lane;
   const double *Dg = ws + pl.o_D, *Eg = ws + pl.o_E;
@@ -577,7 +614,11 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
 #pragma unroll
   for (int k = 0; k < 15; k++) v[k] = 0.0;
   // 0 pr 1 nz 2 nax 3 prs 4 nzs 5 naxs 6 dr 7 nq 8 naty 9 npx 10 drs 11 nqs 12 natys 13 npxs | 14 obj (sum)
-  ell_rows_w<NW>(pl.A, cx.coA, valA, cx.X, wid, lane, [&](int i, double ax) {
+  auto rows_A = [&](auto &&f) {
+    if constexpr (GATHERS) { for (int c = wid; c < pl.A.nchunks; c += NW) f(c * WAVE + lane, ell_chunk_g<8>(valA, pl.A.idx, cx.X, cx.coA[c], cx.coA[c + 1], lane)); }
+    else ell_rows_w<NW>(pl.A, cx.coA, valA, cx.X, wid, lane, f);
+  };
+  rows_A([&](int i, double ax) {
     if (i < pl.m) {
       const double einv = unscale ? 1.0 / Eg[i] : 1.0, zi = cx.Z[i];
       v[0] = fmax(v[0], fabs(einv * (ax - zi))); v[2] = fmax(v[2], fabs(einv * ax)); v[1] = fmax(v[1], fabs(einv * zi));
@@ -587,8 +628,8 @@ __device__ __forceinline__ void update_info_res(RCtx &cx, Info &in) {
   // P x and A' y land on the same rows for a given wave (both chunked by wid), so no barrier is needed in between
   for (int c = wid; c < pl.P.nchunks; c += NW) {
     const int la = lane;
-    const double px = ell_chunk<false>(valP, pl.P.idx, cx.X, cx.coP[c], cx.coP[c + 1], la);
-    const double aty = ell_chunk<false>(valAt, pl.At.idx, cx.Y, cx.coAt[c], cx.coAt[c + 1], la);
+    const double px = GATHERS ? ell_chunk_g<8>(valP, pl.P.idx, cx.X, cx.coP[c], cx.coP[c + 1], la) : ell_chunk<false>(valP, pl.P.idx, cx.X, cx.coP[c], cx.coP[c + 1], la);
+    const double aty = GATHERS ? ell_chunk_g<8>(valAt, pl.At.idx, cx.Y, cx.coAt[c], cx.coAt[c + 1], la) : ell_chunk<false>(valAt, pl.At.idx, cx.Y, cx.coAt[c], cx.coAt[c + 1], la);
     const int t = c * WAVE + lane;
     if (t < pl.npad) {
       const double dinv = unscale ? 1.0 / Dg[t] : 1.0, qv = cx.Q[t], du = qv + px + aty;
