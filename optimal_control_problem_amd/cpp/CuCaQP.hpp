@@ -6,8 +6,9 @@
 //     -> [ setSystem(P,q,A,l,u) -> initSolver -> solve -> getSolution ]  per SQP iteration
 // compiles unchanged against it.  Same bool-return + std::cerr error behaviour (reference
 // src/sqp_solver/CuCaQP.cpp); values stay fp64 (the reference's OSQP build is float, cpu_install.sh:44).
-// The always-available overloads take raw CSC (colptr, rowidx, values) and dense pointers; the CasADi / Eigen
-// overloads of the reference are compiled only where those headers exist (they do not in this image).
+// The always-available overloads take raw CSC (colptr, rowidx, values) and dense pointers; the CasADi and the Eigen
+// overloads of the reference are compiled only where those headers exist (they do not in this image: the tests compile them against
+// tests/support/casadi_mock and tests/support/eigen_mock).
 // One object may hold a batch of QPs of one sparsity (value arrays instance-major); batch = 1 is the drop-in case.
 #pragma once
 #include <algorithm>
@@ -21,6 +22,11 @@
 #if __has_include(<casadi/casadi.hpp>)
 #include <casadi/casadi.hpp>
 #define MPCQP_HAVE_CASADI 1
+#endif
+#if __has_include(<Eigen/Sparse>)
+#include <Eigen/Dense>
+#include <Eigen/Sparse>
+#define MPCQP_HAVE_EIGEN 1
 #endif
 #endif
 
@@ -152,7 +158,17 @@ class CuCaQP {
     return true;
   }
 
-  const std::vector<double> &getSolution() const { return solution_; }   // reference CuCaQP.cpp:213-215
+#ifdef MPCQP_HAVE_EIGEN
+  // reference CuCaQP.h:76 / CuCaQP.cpp:213-215: the primal solution as an Eigen column (instance 0; fp64 where the reference's OSQP build is float)
+  Eigen::Matrix<double, Eigen::Dynamic, 1> getSolution() const {
+    Eigen::Matrix<double, Eigen::Dynamic, 1> x((long)numOfVariables_);
+    for (int j = 0; j < numOfVariables_ && (size_t)j < solution_.size(); j++) x[j] = solution_[j];
+    return x;
+  }
+#else
+  const std::vector<double> &getSolution() const { return solution_; }   // reference CuCaQP.cpp:213-215 (an Eigen column where <Eigen/Sparse> exists)
+#endif
+  const std::vector<double> &getSolutionVector() const { return solution_; }      // every instance of the batch, instance-major
   const std::vector<int> &getStatus() const { return status_; }
   const std::vector<int> &getIterations() const { return iters_; }
 
@@ -163,6 +179,32 @@ class CuCaQP {
     for (int j = 0; j < numOfVariables_; j++) for (int p = Pp_[j]; p < Pp_[j + 1]; p++) std::cout << "P(" << Pi_[p] << "," << j << "): " << Pv_[p] << std::endl;
     for (int j = 0; j < numOfVariables_; j++) for (int p = Ap_[j]; p < Ap_[j + 1]; p++) std::cout << "A(" << Ai_[p] << "," << j << "): " << Av_[p] << std::endl;
   }
+
+#ifdef MPCQP_HAVE_EIGEN
+  // Eigen overloads of the reference (CuCaQP.h:37, 49, 51, 53, 55), for any scalar type (the reference's OSQPFloat is float, cpu_install.sh:44; values are
+  // widened to fp64): same checks, same messages, same bool returns as the raw-pointer forms they forward to.  A sparse matrix must be compressed
+  // column-major storage (what the reference's converter produces with makeCompressed, CuCaQP.h:105-137).
+  template <class T>
+  bool setHessianMatrix(const Eigen::SparseMatrix<T> &P) { EigenCsc<T> c(P); return c.ok && setHessianMatrix(c.view()); }
+  template <class T>
+  bool setLinearConstraintsMatrix(const Eigen::SparseMatrix<T> &A) { EigenCsc<T> c(A); return c.ok && setLinearConstraintsMatrix(c.view()); }
+  template <class T>
+  bool setGradient(const Eigen::Matrix<T, Eigen::Dynamic, 1> &q) { const std::vector<double> v(q.data(), q.data() + q.size()); return setGradient(v.data(), (int)v.size()); }
+  template <class T>
+  bool setLowerBound(const Eigen::Matrix<T, Eigen::Dynamic, 1> &l) { const std::vector<double> v(l.data(), l.data() + l.size()); return setLowerBound(v.data(), (int)v.size()); }
+  template <class T>
+  bool setUpperBound(const Eigen::Matrix<T, Eigen::Dynamic, 1> &u) { const std::vector<double> v(u.data(), u.data() + u.size()); return setUpperBound(v.data(), (int)v.size()); }
+  template <class T>
+  struct EigenCsc {      // index arrays as int, values as double, for the life of one call (the setters copy)
+    bool ok; int rows, cols; std::vector<int> cp, ri; std::vector<double> val;
+    explicit EigenCsc(const Eigen::SparseMatrix<T> &M) : ok(M.isCompressed()), rows((int)M.rows()), cols((int)M.cols()) {
+      if (!ok) { std::cerr << "Error: sparse matrix is not in compressed storage. Call makeCompressed() first." << std::endl; return; }
+      cp.assign(M.outerIndexPtr(), M.outerIndexPtr() + M.cols() + 1); ri.assign(M.innerIndexPtr(), M.innerIndexPtr() + M.nonZeros());
+      val.assign(M.valuePtr(), M.valuePtr() + M.nonZeros());
+    }
+    CscView view() const { return CscView{rows, cols, cp.data(), ri.data(), val.data()}; }
+  };
+#endif
 
 #ifdef MPCQP_HAVE_CASADI
   // CasADi overloads of the reference (CuCaQP.h:38-48, converters CuCaQP.h:105-152): DM is CSC already.

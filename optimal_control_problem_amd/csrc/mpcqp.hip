@@ -55,6 +55,7 @@ int mpcqp_pick_device(int requested, int *device) {
 
 struct mpcqp_handle {
   int n = 0, m = 0, batch = 0, device = 0;
+  hipEvent_t ev_guard = nullptr;              // mpcqp_order_after_last_solve
   mpcqp_settings st;
   Plan plan; WsLayout wl; long lds = 0;
   int variant = 0;              // 0 = streaming (1 wave / QP), NW > 0 = LDS-resident factor with NW waves / QP
@@ -93,6 +94,15 @@ struct mpcqp_handle {
   // reduced form (mpcqp_create_reduced): this handle keeps the caller's dimensions, `inner` solves the QP without the eliminated variables
   mpcqp_handle *inner = nullptr; RedMaps red; DevRed dred; double *rx0 = nullptr, *ry0 = nullptr;
 };
+
+int mpcqp_order_after_last_solve(mpcqp_handle *h, hipStream_t s) {
+  if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+  if (!h->solved || h->last_stream == s) return MPCQP_OK;
+  if (!h->ev_guard) HIPCHK(hipEventCreateWithFlags(&h->ev_guard, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->ev_guard, h->last_stream));
+  HIPCHK(hipStreamWaitEvent(s, h->ev_guard, 0));
+  return MPCQP_OK;
+}
 
 template <class T>
 static int upload(mpcqp_handle *h, const std::vector<T> &v, const T **out) {
@@ -525,7 +535,10 @@ int mpcqp_create_tuned(int n, int m, int batch, const int *Pp, const int *Pi, co
   if (!out) return fail(MPCQP_ERR_ARG, "out is null");
   *out = nullptr;
   if (n <= 0 || m < 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  if (Pp[0] != 0 || Ap[0] != 0) return fail(MPCQP_ERR_ARG, "colptr must start at 0");
   for (int j = 0; j < n; j++) if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) return fail(MPCQP_ERR_ARG, "colptr not monotone");
+  for (int k = 0; k < Pp[n]; k++) if (Pi[k] < 0 || Pi[k] >= n) return fail(MPCQP_ERR_ARG, "P row index out of range");      // (before the pattern is hashed and a synthetic QP filled through it)
+  for (int k = 0; k < Ap[n]; k++) if (Ai[k] < 0 || Ai[k] >= m) return fail(MPCQP_ERR_ARG, "A row index out of range");
   struct Force { const char *prev; explicit Force(const char *v) : prev(g_force_variant) { g_force_variant = v; } ~Force() { g_force_variant = prev; } };
   mpcqp_settings st; if (settings) st = *settings; else mpcqp_default_settings(&st);
   int dev = st.device; if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -533,7 +546,13 @@ int mpcqp_create_tuned(int n, int m, int batch, const int *Pp, const int *Pi, co
   {
     std::string cached;
     { std::lock_guard<std::mutex> lock(g_tune_mu); auto it = g_tune_cache.find(key); if (it != g_tune_cache.end()) cached = it->second; }
-    if (!cached.empty()) { Force f(cached == "rule" ? "" : cached.c_str()); return mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out); }
+    if (!cached.empty()) {
+      int rc;
+      { Force f(cached == "rule" ? "" : cached.c_str()); rc = mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out); }
+      if (rc != MPCQP_ERR_LIMIT || cached == "rule") return rc;
+      Force f("");       // the cached family no longer takes the size (other settings): the rule's choice instead of an error
+      return mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out);
+    }
   }
   // the synthetic QP on this pattern: P = unit diagonal (other entries 0: positive semidefinite whatever the pattern), A pseudo-random in
   // [-1, 1], q pseudo-random, -1 <= A x <= 1 (feasible at the origin); one instance shared by the batch (stride 0)
@@ -934,6 +953,7 @@ void mpcqp_destroy(mpcqp_handle *h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+  if (h->ev_guard) (void)hipEventDestroy(h->ev_guard);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->ev0r) (void)hipEventDestroy(h->ev0r);
   for (int i = 0; i < mpcqp_handle::NPIPE; i++) if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);

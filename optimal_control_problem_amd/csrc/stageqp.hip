@@ -181,6 +181,7 @@ int mpcqp_stageqp_update(mpcqp_stageqp *s, const double *H, const double *Hp, co
   }
   const int nP = (int)p.Pi.size(), nA = (int)p.Ai.size();
   const long total = ((long)nP + nA) * s->batch;
+  { int rc = mpcqp_order_after_last_solve(s->h, st); if (rc) return rc; }      // the packed P, A are rewritten below: a solve on another stream may still read them
   hipLaunchKernelGGL(stageqp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s->batch, nP, nA, s->dsrcP, s->dsrcA,
                      H, sH, Hp, sHp, Hpp, sHpp, AB, sAB, s->dP, s->dA);
   MPCQP_HIPCHK(hipGetLastError());

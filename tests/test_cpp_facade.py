@@ -46,6 +46,27 @@ def test_cpp_facade_casadi_call_sequence_on_gpu(built):
     assert "iteration 1" in r.stdout
 
 
+EIGEN_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "cucaqp_eigen_test")
+
+
+def test_cpp_facade_eigen_overloads_compile_and_refuse_without_gpu(built):
+    """the Eigen overloads of cpp/CuCaQP.hpp (reference CuCaQP.h:37,49,51,53,55 and the Eigen-returning getSolution :76) compiled against
+    tests/support/eigen_mock: exit code 2 would mean they were not compiled at all"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; see the gpu-marked test")
+    r = subprocess.run([EIGEN_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_facade_eigen_overloads_on_gpu(built):
+    """each Eigen overload called on the GPU (float = the reference's OSQPFloat, and double), then refused with a wrong dimension"""
+    r = subprocess.run([EIGEN_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.count("Eigen overloads") == 2 and "mismatch" in r.stderr
+
+
 SQP_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "stagesqp_cpp_test")
 
 

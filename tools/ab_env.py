@@ -23,12 +23,12 @@ for cs in cases:
         if on:
             os.environ[var] = "1"
         qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
-        os.environ.pop(var, None)
         qp.set_dispatch_hint(False)
         ms = []
         for _ in range(5):
             qp.update(*d); qp.solve(); torch.cuda.synchronize(); ms.append(qp.last_kernel_ms())
         got = qp.get(); v = qp.plan_info()["variant"]; qp.close()
+        os.environ.pop(var, None)      # (only now: some switches are read at every solve)
         res[tag] = got
         print("%-18s N=%3d x %5d %-16s variant %3d: kernel %.3f ms (min of %s)" % (name, N, B, tag, v, min(ms[1:]), " ".join("%.3f" % m for m in ms)), flush=True)
     a, b = res["default"], res[var + "=1"]

@@ -10,7 +10,7 @@ def rows(path):
         name = blk.split()[0]
         g = lambda k: int(re.search(k + r": (\d+)", blk).group(1))
         try:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip().split("(")[0] or name
+            name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0] or name
         except OSError:
             pass
         yield dict(kernel=name.replace("void ", ""), vgpr=g("VGPRs"), agpr=g("AGPRs"), scratch=g(r"ScratchSize \[bytes/lane\]"),
