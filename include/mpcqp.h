@@ -107,6 +107,17 @@ int mpcqp_create_reduced(int n, int m, int batch,
                          int nfixed, const int *fixed_rows,
                          const mpcqp_settings *settings, mpcqp_handle **out);
 
+/* The same without the caller naming rows: the rows to eliminate are FOUND -- every row of A with a single entry whose bounds coincide in every
+ * instance of (l, u), the bounds of the first update (host or device arrays, strides as in mpcqp_update; read once, here) -- which is what the
+ * reference's formulation produces by itself: 0 <= dp <= 0 on the parameter block (SQPOptimizationSolver.cpp:117) and the first frame pinned
+ * through lbx = ubx (src/OptimalControlProblem.cpp:93-96).  A caller that arrives through CuCaQP / OptimalControlProblem and cannot name rows
+ * gets the reduced form this way (CuCaQP::setPresolveFixedRows(true) in cpp/CuCaQP.hpp).  Returns the handle of mpcqp_create_reduced on those rows
+ * (an ordinary handle when there are none) and their number in *nfixed (may be NULL).  The promise "l = u on these rows in every later update" is
+ * checked per instance as there (MPCQP_UNSOLVED, NaN for an instance that breaks it).  The default stays the full form. */
+int mpcqp_create_presolved(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                           const double *l, long sl, const double *u, long su, int mem,
+                           const mpcqp_settings *settings, mpcqp_handle **out, int *nfixed);
+
 /* Replaces CuCaQP::setSystem -> setHessianMatrix/setGradient/setLinearConstraintsMatrix/setLowerBound/
  * setUpperBound (CuCaQP.cpp:43-103,271-288), argument order P,q,A,l,u as at CuCaQP.cpp:283-287.
  * Value arrays are instance-major: QP b reads P + b*strideP (in doubles) ... ; stride 0 shares one array

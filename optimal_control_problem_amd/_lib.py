@@ -14,7 +14,7 @@ OK, ERR_ARG, ERR_HIP, ERR_NO_GPU, ERR_STATE, ERR_LIMIT = 0, 1, 2, 3, 4, 5
 STATUS = {1: "solved", 2: "solved_inaccurate", 3: "primal_infeasible", 4: "primal_infeasible_inaccurate",
           5: "dual_infeasible", 6: "dual_infeasible_inaccurate", 7: "max_iter_reached", 9: "non_cvx", 11: "unsolved"}
 
-EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_create_tuned", "mpcqp_create_reduced", "mpcqp_update", "mpcqp_warm_start", "mpcqp_keep_workspace", "mpcqp_update_vectors", "mpcqp_set_rho", "mpcqp_set_dispatch_hint", "mpcqp_solve", "mpcqp_solve_host",
+EXPORTS = ["mpcqp_default_settings", "mpcqp_create", "mpcqp_create_tuned", "mpcqp_create_reduced", "mpcqp_create_presolved", "mpcqp_update", "mpcqp_warm_start", "mpcqp_keep_workspace", "mpcqp_update_vectors", "mpcqp_set_rho", "mpcqp_set_dispatch_hint", "mpcqp_solve", "mpcqp_solve_host",
            "mpcqp_get", "mpcqp_sync", "mpcqp_destroy", "mpcqp_strerror", "mpcqp_last_kernel_ms", "mpcqp_last_phase_ms",
            "mpcqp_plan_info", "mpcqp_oc_info", "mpcqp_debug_scaling", "mpcqp_debug_blockops",
            "mpcqp_stage_default", "mpcqp_stage_create", "mpcqp_stage_create_user", "mpcqp_stage_destroy", "mpcqp_stage_set_weights", "mpcqp_stage_set_path_bounds", "mpcqp_stage_dims", "mpcqp_stage_has_cost", "mpcqp_stage_pattern",
@@ -70,6 +70,7 @@ def lib():
         L.mpcqp_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(vp)]
         L.mpcqp_create_tuned.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(vp)]
         L.mpcqp_create_reduced.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.POINTER(Settings), C.POINTER(vp)]
+        L.mpcqp_create_presolved.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, dp, lg, dp, lg, C.c_int, C.POINTER(Settings), C.POINTER(vp), C.POINTER(C.c_int)]
         L.mpcqp_update.argtypes = [vp, dp, lg, dp, lg, dp, lg, dp, lg, dp, lg, C.c_int]
         L.mpcqp_warm_start.argtypes = [vp, dp, dp, C.c_int]
         L.mpcqp_set_rho.argtypes = [vp, dp, C.c_int]

@@ -41,9 +41,10 @@ def _ptr_stride(a, width, batch, name):
 
 
 class BatchQP:
-    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, fixed_rows=None, tuned=False, **kw):
+    def __init__(self, n, m, batch, Pp, Pi, Ap, Ai, settings=None, fixed_rows=None, tuned=False, presolve_bounds=None, **kw):
         """fixed_rows: opt-in reduced form (mpcqp_create_reduced) -- singleton rows of A with l = u in every instance, whose
         variables are substituted before the solve; None (default) = the full form, what the reference's OSQP solves.
+        presolve_bounds = (l, u): the same with the rows FOUND from the first update's bounds (mpcqp_create_presolved); self.nfixed says how many.
         tuned: opt-in mpcqp_create_tuned -- the kernel family chosen by measurement on this pattern instead of by rule"""
         self.n, self.m, self.batch = int(n), int(m), int(batch)
         self.Pp = np.ascontiguousarray(Pp, dtype=np.int32); self.Pi = np.ascontiguousarray(Pi, dtype=np.int32)
@@ -54,7 +55,16 @@ class BatchQP:
         self._h = C.c_void_p()
         self._keep = []
         L = _lib.lib()
-        if fixed_rows is None:
+        self.nfixed = 0
+        if presolve_bounds is not None:
+            lp, ls_, lmem, lk = _ptr_stride(presolve_bounds[0], self.m, self.batch, "l"); up, us_, umem, uk = _ptr_stride(presolve_bounds[1], self.m, self.batch, "u")
+            if lmem != umem:
+                raise ValueError("l and u must live in the same memory space")
+            nf = C.c_int(0)
+            _lib.check(L.mpcqp_create_presolved(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data, self.Ap.ctypes.data, self.Ai.ctypes.data,
+                                                lp, ls_, up, us_, lmem, C.byref(self.settings), C.byref(self._h), C.byref(nf)))
+            self.nfixed = int(nf.value)
+        elif fixed_rows is None:
             _lib.check((L.mpcqp_create_tuned if tuned else L.mpcqp_create)(self.n, self.m, self.batch, self.Pp.ctypes.data, self.Pi.ctypes.data,
                                       self.Ap.ctypes.data, self.Ai.ctypes.data, C.byref(self.settings), C.byref(self._h)))
         else:

@@ -53,6 +53,11 @@ class CuCaQP {
   void setRelativeTolerance(double tolerance) { settings_.eps_rel = tolerance; dirty_ = true; }
   void setMaxIteration(int maxIteration) { settings_.max_iter = maxIteration; dirty_ = true; }
   mpcqp_settings &settings() { dirty_ = true; return settings_; }
+  // opt-in: variables that a singleton row pins (l = u in every instance: the reference's 0 <= dp <= 0 rows, SQPOptimizationSolver.cpp:117, and the
+  // first frame, OptimalControlProblem.cpp:93-96) are found from the bounds at initSolver() and substituted before the solve
+  // (mpcqp_create_presolved).  An equivalent QP, a shorter ADMM run; the default (false) solves the QP as OSQP does.
+  void setPresolveFixedRows(bool on) { if (on != presolve_) { presolve_ = on; dirty_ = true; } }
+  int presolvedRows() const { return nfixed_; }
 
   // data, reference CuCaQP.cpp:43-103 (values are copied, like the reference copies into its members CuCaQP.h:83-87)
   bool setHessianMatrix(const CscView &P) {
@@ -127,7 +132,10 @@ class CuCaQP {
     int rc = MPCQP_OK;
     if (!handle_ || patternChanged_ || dirty_) {
       clearSolver();
-      rc = mpcqp_create(numOfVariables_, numOfConstraints_, batch_, Pp_.data(), Pi_.data(), Ap_.data(), Ai_.data(), &settings_, &handle_);
+      nfixed_ = 0;
+      rc = presolve_ ? mpcqp_create_presolved(numOfVariables_, numOfConstraints_, batch_, Pp_.data(), Pi_.data(), Ap_.data(), Ai_.data(), l_.data(), numOfConstraints_,
+                                              u_.data(), numOfConstraints_, MPCQP_MEM_HOST, &settings_, &handle_, &nfixed_)
+                     : mpcqp_create(numOfVariables_, numOfConstraints_, batch_, Pp_.data(), Pi_.data(), Ap_.data(), Ai_.data(), &settings_, &handle_);
       patternChanged_ = dirty_ = false;
       kept_ = rc == MPCQP_OK && mpcqp_keep_workspace(handle_, 1) == MPCQP_OK;   // not on the streaming kernel variant
     }
@@ -276,7 +284,8 @@ class CuCaQP {
 
   int batch_ = 1, numOfVariables_ = 0, numOfConstraints_ = 0;
   bool isInitialized_ = false, verbose_ = false, patternChanged_ = true, dirty_ = false;
-  bool kept_ = false, vectorsOnly_ = false, matricesDirty_ = false, solvedOnce_ = false;
+  bool kept_ = false, vectorsOnly_ = false, matricesDirty_ = false, solvedOnce_ = false, presolve_ = false;
+  int nfixed_ = 0;
   mpcqp_settings settings_;
   mpcqp_handle *handle_ = nullptr;
   std::vector<int> Pp_, Pi_, Ap_, Ai_, status_, iters_;

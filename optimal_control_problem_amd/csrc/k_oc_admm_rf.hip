@@ -11,6 +11,8 @@ MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm_rf(int nw, int ng, int nh) {
   if (nw == 8) {
     if (ng == OC8_INST[0].ng && nh == OC8_INST[0].nh) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[0].ng, OC8_INST[0].nh, RF>;
     if (ng == OC8_INST[1].ng && nh == OC8_INST[1].nh) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[1].ng, OC8_INST[1].nh, RF>;
+    if (ng == OC8_INST[0].ng && nh == 0) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[0].ng, 0, RF>;      // no arrow head (the reduced form's long chains)
+    if (ng == OC8_INST[1].ng && nh == 0) return (const void *)mpcqp_oc_admm_kernel<8, OC8_INST[1].ng, 0, RF>;
   }
   return nullptr;
 }

@@ -18,7 +18,7 @@ MPCQP_HIDDEN const void *KFN(int nw, int ng, int nh, bool tiles) {
       return tiles ? (const void *)mpcqp_res_kernel<8, 2, true, R, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh, true>
                    : (const void *)mpcqp_res_kernel<8, 2, true, R, OC8_INST[1].zyg, OC8_INST[1].ng, OC8_INST[1].nh>;
     }
-    return nullptr;
+    return nullptr;      // (patterns without an arrow head: the two-kernel form only)
   }
   if (nw != 4 || ng != OC_NG) return nullptr;
   if (tiles) return nh == OC_NH ? (const void *)mpcqp_res_kernel<4, 2, true, R, false, OC_NG, OC_NH, true> : nullptr;

@@ -142,7 +142,7 @@ static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
   auto lds = [&](int nw, int minw) { return reuse ? mpcqp_kernel_res_lds_r1(nw, minw) : mpcqp_kernel_res_lds_r0(nw, minw); };
   auto gb = [&](int nw, int minw, bool zyg) { return reuse ? mpcqp_kernel_res_gb_r1(nw, minw, zyg) : mpcqp_kernel_res_gb_r0(nw, minw, zyg); };
   auto mono = [&](int nw, int ng, int nh) { return reuse ? mpcqp_kernel_oc_mono_r1(nw, ng, nh, h->tiles) : mpcqp_kernel_oc_mono_r0(nw, ng, nh, h->tiles); };
-  if (h->oc && h->oc8) return mono(8, OC8_INST[h->oc8 - 1].ng, OC8_INST[h->oc8 - 1].nh);
+  if (h->oc && h->oc8) return mono(8, OC8_INST[h->oc8 - 1].ng, OC8_INST[h->oc8 - 1].nh);      // (nullptr without an arrow head: such handles run the two-kernel form)
   if (h->oc) return mono(4, OC_NG, h->ocplan.has_hub ? OC_NH : 0);
   if (h->gblocks && h->variant == 2) return gb(2, 3, false);
   if (h->gblocks && h->zyg) return gb(4, h->occ3 ? 3 : 2, true);
@@ -158,7 +158,7 @@ static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
 // the two kernels of the on-chip mode (kernel_oc_split.hpp): CuCaQP::initSolver and CuCaQP::solve
 static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->oc8 ? 8 : 4, h->ocplan.has_hub != 0, reuse); }
 static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
-  const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = h->oc8 ? OC8_INST[h->oc8 - 1].nh : (h->ocplan.has_hub ? OC_NH : 0);
+  const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = !h->ocplan.has_hub ? 0 : h->oc8 ? OC8_INST[h->oc8 - 1].nh : OC_NH;
   return rf ? mpcqp_kernel_oc_admm_rf(nw, ng, nh) : mpcqp_kernel_oc_admm(nw, ng, nh);
 }
 // One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
@@ -322,7 +322,8 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         const ResPlan r8 = build_res_plan(p8, 8, false);
         for (int k = 0; k < 2 && !h->oc8; k++) {
           const OcPlan o = build_oc_plan(p8, 8, 1 << 20, OC8_INST[k].ng, OC8_INST[k].nh, OC8_MAX_CHAIN);
-          if (o.ok && o.has_hub && lds_bytes_oc(p8, r8, o, OC8_INST[k].zyg) <= OC8_LDS_MAX) {
+          // (a pattern without an arrow head -- the reduced form -- runs the same instances with no hub block: two-kernel form only)
+          if (o.ok && (o.has_hub || !getenv("MPCQP_OC_MONO")) && lds_bytes_oc(p8, r8, o, OC8_INST[k].zyg) <= OC8_LDS_MAX) {
             h->ocplan = o; h->oc8 = k + 1; h->oc = true; h->gblocks = true; h->zyg = OC8_INST[k].zyg; want = 8; p4 = p8;
           }
         }
@@ -652,6 +653,49 @@ int mpcqp_create_reduced(int n, int m, int batch, const int *Pp, const int *Pi, 
   if (hipEventCreateWithFlags(&h->ev0r, hipEventDisableTiming) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   *out = h;
   return MPCQP_OK;
+}
+
+int mpcqp_create_presolved(int n, int m, int batch, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                           const double *l, long sl, const double *u, long su, int mem,
+                           const mpcqp_settings *settings, mpcqp_handle **out, int *nfixed_out) {
+  if (!out) return fail(MPCQP_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (nfixed_out) *nfixed_out = 0;
+  if (n <= 0 || m <= 0 || batch <= 0 || !Pp || !Pi || !Ap || !Ai || !l || !u) return fail(MPCQP_ERR_ARG, "Invalid dimensions.");
+  if (sl < 0 || su < 0 || (sl && sl < m) || (su && su < m)) return fail(MPCQP_ERR_ARG, "stride smaller than the array it strides (dimension mismatch)");
+  if (mem != MPCQP_MEM_HOST && mem != MPCQP_MEM_DEVICE) return fail(MPCQP_ERR_ARG, "mem must be MPCQP_MEM_HOST or MPCQP_MEM_DEVICE");
+  if (Ap[0] != 0) return fail(MPCQP_ERR_ARG, "colptr must start at 0");
+  for (int j = 0; j < n; j++) {
+    if (Ap[j + 1] < Ap[j]) return fail(MPCQP_ERR_ARG, "colptr not monotone");
+    for (int k = Ap[j]; k < Ap[j + 1]; k++) if (Ai[k] < 0 || Ai[k] >= m) return fail(MPCQP_ERR_ARG, "A row index out of range");
+  }
+  // the bounds of the first update on the host (device arrays: one copy, at creation only)
+  const size_t nl = sl ? (size_t)sl * (batch - 1) + m : (size_t)m, nu = su ? (size_t)su * (batch - 1) + m : (size_t)m;
+  std::vector<double> hl, hu;
+  if (mem == MPCQP_MEM_DEVICE) {
+    hl.resize(nl); hu.resize(nu);
+    HIPCHK(hipMemcpy(hl.data(), l, nl * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hu.data(), u, nu * sizeof(double), hipMemcpyDeviceToHost));
+    l = hl.data(); u = hu.data();
+  }
+  // rows with a single entry in A whose bounds coincide in EVERY instance; one row per variable (a second one stays an ordinary row)
+  std::vector<int> cnt(m, 0), col(m, -1);
+  for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) { cnt[Ai[k]]++; col[Ai[k]] = j; }
+  std::vector<char> taken(n, 0);
+  std::vector<int> rows;
+  for (int i = 0; i < m; i++) {
+    if (cnt[i] != 1 || taken[col[i]]) continue;
+    bool eq = true;
+    for (int b = 0; b < (sl || su ? batch : 1) && eq; b++) {
+      const double lo = l[(size_t)b * sl + i], up = u[(size_t)b * su + i];
+      eq = std::fabs(up - lo) <= 1e-9 * std::max(1.0, std::fabs(lo)) && std::fabs(lo) < 1e20;      // (the presolve kernel's own test of the promise)
+    }
+    if (eq) { rows.push_back(i); taken[col[i]] = 1; }
+  }
+  if (nfixed_out) *nfixed_out = (int)rows.size();
+  if ((int)rows.size() >= n) rows.resize(n - 1);       // (a QP with every variable fixed keeps one: the reduced pattern needs a variable)
+  if (rows.empty()) return mpcqp_create(n, m, batch, Pp, Pi, Ap, Ai, settings, out);      // nothing to eliminate: the ordinary handle
+  return mpcqp_create_reduced(n, m, batch, Pp, Pi, Ap, Ai, (int)rows.size(), rows.data(), settings, out);
 }
 
 // the solve of a reduced handle: substitute the fixed variables, hand the smaller QP to the inner handle, expand its result

@@ -34,5 +34,16 @@ int main() {
   const double Pv2[] = {8.0, 4.0};
   if (!qp.updateHessianMatrix({2, 2, Pp, Pi, Pv2}) || !qp.solve()) return 1;
   std::printf("x = %.6f %.6f status %d iters %d\n", x[0], x[1], qp.getStatus()[0], qp.getIterations()[0]);
-  return (std::fabs(x[0] - 5.0 / 6.0) < 5e-3 && std::fabs(x[1] - 7.0 / 6.0) < 5e-3) ? 0 : 1;
+  if (!(std::fabs(x[0] - 5.0 / 6.0) < 5e-3 && std::fabs(x[1] - 7.0 / 6.0) < 5e-3)) return 1;
+  // setPresolveFixedRows (mpcqp_create_presolved): a variable pinned by a singleton row with l = u -- the shape of the reference's dp = 0 rows,
+  // SQPOptimizationSolver.cpp:117 -- is found from the bounds and substituted: x1 = 0.3 exactly, x2 = 0.7 from x1 + x2 = 1
+  CuCaQP pq;
+  if (!pq.setDimension(2, 3)) return 1;
+  pq.setAbsoluteTolerance(1e-3); pq.setRelativeTolerance(1e-3); pq.setMaxIteration(10000); pq.setPresolveFixedRows(true);
+  const double lp[] = {0.3, -100, 1}, up[] = {0.3, 100, 1};
+  pq.setSystem({2, 2, Pp, Pi, Pv}, q, {3, 2, Ap, Ai, Av}, lp, up);
+  if (!pq.initSolver() || !pq.solve()) return 1;
+  const auto &xp = pq.getSolution();
+  std::printf("presolved rows %d: x = %.6f %.6f status %d\n", pq.presolvedRows(), xp[0], xp[1], pq.getStatus()[0]);
+  return (pq.presolvedRows() == 1 && xp[0] == 0.3 && std::fabs(xp[1] - 0.7) < 5e-3 && pq.getStatus()[0] == MPCQP_SOLVED) ? 0 : 1;
 }

@@ -893,6 +893,45 @@ def test_reduced_form(built, name, B, N, first_frame):
     qp.close()
 
 
+@pytest.mark.parametrize("name,B,N,variant", [("quadrotor", 8, 20, 204), ("cartpole", 6, 30, None), ("quadrotor", 4, 50, 208), ("cartpole", 4, 100, None)])
+def test_presolved_create_finds_the_rows(built, name, B, N, variant):
+    """mpcqp_create_presolved: the rows a caller of the reference's formulation cannot name -- 0 <= dp <= 0 on the parameter block
+    (SQPOptimizationSolver.cpp:117) and the first frame pinned through lbx = ubx (OptimalControlProblem.cpp:93-96) -- are found from the bounds of
+    the first update.  (a) exactly the singleton rows with l = u in every instance; (b) the handle is the one mpcqp_create_reduced gives for those
+    rows: bitwise the same results; (c) oracle parity on the reduced QP at the tight bar; (d) long chains stay on chip without an arrow head
+    (variant 208); (e) the same optimum as the full form at a tight tolerance"""
+    from optimal_control_problem_amd.batch_qp import BatchQP, solve_local_system
+    mdl, ls, meta = models.make_workload(name, B, N=N)
+    Pd, Ad = ls.dense(0)
+    single = [i for i in range(ls.m) if (Ad[i] != 0).sum() == 1]
+    rows = [i for i in single if (ls.l[:, i] == ls.u[:, i]).all()]
+    assert len(rows) >= mdl.np + mdl.nx
+    qp = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, presolve_bounds=(ls.l, ls.u))
+    assert qp.nfixed == len(rows)
+    if variant:
+        assert qp.plan_info()["variant"] == variant
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    qn = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=rows)
+    qn.update(ls.P, ls.q, ls.A, ls.l, ls.u); qn.solve(); named = qn.get(); qn.close()
+    for k in ("x", "y", "z", "status", "iters"):
+        assert np.array_equal(got[k], named[k], equal_nan=True), k
+    red, free, kept, fvars, xfix = problems.reduce_qp(ls, rows)
+    ref = problems.oracle_solve(red)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    tol = lambda a: 1e-6 * (1.0 + np.abs(a).max())
+    assert np.abs(got["x"][:, free] - ref["x"]).max() <= tol(ref["x"]) and np.abs(got["y"][:, kept] - ref["y"]).max() <= tol(ref["y"])
+    assert np.array_equal(got["x"][:, fvars], xfix)
+    tight = dict(eps_abs=1e-9, eps_rel=1e-9)
+    qt = BatchQP(ls.n, ls.m, B, ls.Pp, ls.Pi, ls.Ap, ls.Ai, presolve_bounds=(ls.l, ls.u), **tight)
+    qt.update(ls.P, ls.q, ls.A, ls.l, ls.u); qt.solve(); gt = qt.get(); qt.close()
+    full = solve_local_system(ls, **tight)
+    both = (full["status"] == 1) & (gt["status"] == 1)      # (at 1e-9 the long cart-pole horizon stops at max_iter in one form or the other: compared where both arrive)
+    if N <= 50:
+        assert both.all()
+    if both.any():
+        assert np.abs(gt["x"][both] - full["x"][both]).max() <= 1e-4 * (1.0 + np.abs(full["x"][both]).max())
+
+
 def test_reduced_form_refuses_what_it_must(built):
     from optimal_control_problem_amd import _lib
     from optimal_control_problem_amd.batch_qp import BatchQP
