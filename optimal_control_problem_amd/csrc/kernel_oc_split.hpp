@@ -463,7 +463,10 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
         for (int t = tid; t < npad; t += NT) { const double xo = cx.X[t]; dxg[t] = __builtin_fma(alpha, cx.R[t], (1.0 - alpha) * xo) - xo; }
       }
       for (int t = tid; t < npad; t += NT) cx.X[t] = __builtin_fma(alpha, cx.R[t], (1.0 - alpha) * cx.X[t]);
-      bsync<NW>();
+      // (no barrier here in an ordinary iteration: x_t is next read by the thread that wrote it -- the A' sweep hands out the same indices --, R is not
+      // written before that sweep's own rows, and the barrier above already separates them from the A sweep's gathers; only the residual sweeps of a
+      // termination check gather x)
+      if (__builtin_expect(save, 0)) bsync<NW>();
       TS(6);
       iter_done = iter;
       if (__builtin_expect(can_check, 0)) {     // (rare paths are marked cold: their register pressure must not cost the hot loop its registers)

@@ -558,18 +558,10 @@ __device__ __forceinline__ int2 oc_pair(const int *tab, int k) { return *reinter
 // are fetched while the current stage multiplies.  HUB: the pattern has an arrow head (has_hub); its first NH blocks per wave are
 // in registers (the host lays the plan out for exactly this instance).
 // Touch every 128-byte line of [base, base + bytes): one dword per lane and line, results dropped -- brings a slab region that the next
-// phase streams into L2 while this wave has nothing else to do (the wave waits for its own loads: nothing outstanding when it moves on)
-__device__ __forceinline__ void oc_touch(const void *base, const long bytes, const int lane) {
-  const char *p = reinterpret_cast<const char *>(base) + (long)lane * 128;
-  for (long o = 0; o < bytes; o += 64 * 128) {
-    if (o + (long)lane * 128 < bytes) { int t; asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(p + o) : "memory"); }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-// The same with the loads' destination pinned: the compiler does not know that the asm statement above returns its result later -- it may hand
-// the destination register to something else (an address of the next trip) before the load has landed, and whether it does depends on the
-// register allocation of the instance: the round-2 instances happen not to (their ISA was checked: one register, only ever written by these
-// loads), an instance with tiles did, and faulted.  Here every load writes ONE register that stays an operand up to the final wait.
+// phase streams into L2 while this wave has nothing else to do (the wave waits for its own loads: nothing outstanding when it moves on).
+// Every load writes ONE register that stays an operand of the inline assembly up to the final wait: the compiler does not know that a load
+// issued from inline assembly returns its result later, and with a plain output operand it may hand the destination register to something else
+// before the load has landed (round 3 found that on an instance with tiles; the unpinned form is gone).
 __device__ __forceinline__ void oc_touch_pinned(const void *base, const long bytes, const int lane) {
   const char *p = reinterpret_cast<const char *>(base) + (long)lane * 128;
   int sink = 0;

@@ -1025,8 +1025,8 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
       return;
     }
-    if (w == 2) oc_touch(valA, pl.A.entries * 8, lane);
-    else if (NW == 4 || w == 3) { oc_touch(lb, (long)mpad * 8, lane); oc_touch(ub, (long)mpad * 8, lane); oc_touch(valAt, pl.At.entries * 8, lane); }
+    if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
+    else if (NW == 4 || w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
   };
   OcTileRec trec;
   if constexpr (TL) trec = oc_tile_records<NW>(oc.tl, pl.A.nchunks, pl.At.nchunks, wid, lane);      // this wave's chunk records, for the whole solve
