@@ -255,6 +255,29 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       ell_map_chunk<true>(valAt, pl.At.src, inA, pl.At.idx, valAt, cx.coAt[ch], cx.coAt[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
       ell_map_chunk<false>(sP, pl.P.idx, nullptr, pl.P.idx, valP, cx.coP[ch], cx.coP[ch + 1], lane, [&](double v, int k) { return v * (c * dj * cx.R[k]); });
     }
+    if (oc.tl.on) {
+      // the same scaled numbers once more in the layouts of the tile sweeps (experiment, MPCQP_VTILES=1): dense 16 x 16 tiles, row-major (element (r, c)
+      // of tile t is row rowid[16 t + r], position 16 tJ[t] + c), and the two remainder ELL layouts, gathered from the caller's array
+      const DevTile &tl = oc.tl;
+      double *tiles = ws + tl.o_tile, *valAr = ws + tl.o_ellAr, *valAtr = ws + tl.o_ellAtr;
+      for (long e = tid; e < (long)tl.ntile * BLK; e += NT) {
+        const int sidx = tl.tsrc[e];
+        double v = 0.0;
+        if (sidx >= 0) {
+          const int t = (int)(e >> 8), r = (int)(e >> 4) & 15, cc = (int)e & 15;
+          v = inA[sidx] * (cx.W[tl.rowid[t * BS + r]] * cx.R[BS * tl.tJ[t] + cc]);
+        }
+        tiles[e] = v;
+      }
+      for (int ch = wid; ch < tl.nAr; ch += NW) {
+        const int i = ch * WAVE + lane; const double ei = i < mpad ? cx.W[i] : 0.0;
+        ell_map_chunk<true>(valAr, tl.Ar_src, inA, tl.Ar_idx, valAr, tl.Ar_off[ch], tl.Ar_off[ch + 1], lane, [&](double v, int j) { return v * (ei * cx.R[j]); });
+      }
+      for (int ch = wid; ch < tl.nAtr; ch += NW) {
+        const int t = ch * WAVE + lane; const double dj = t < npad ? cx.R[t] : 0.0;
+        ell_map_chunk<true>(valAtr, tl.Atr_src, inA, tl.Atr_idx, valAtr, tl.Atr_off[ch], tl.Atr_off[ch + 1], lane, [&](double v, int i) { return v * (dj * cx.W[i]); });
+      }
+    }
     bsync<NW>();
     for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
     for (int i = tid; i < mpad; i += NT) {
@@ -294,7 +317,8 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
 // Iteration: what osqp_solve does per QP, on the factor the set-up kernel left in the slab.
 // =========================================================================================================
 // RF = 1: an adaptive-rho step re-factorises in place (the last launch of a solve); RF = 0: the instance leaves for the set-up kernel's resume mode
-template <int NW, int OCG, int OCH, int RF>
+// TL: the two sweeps of the iteration on dense tiles of A + remainder ELL layouts (experiment; below)
+template <int NW, int OCG, int OCH, int RF, bool TL = false>
 __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * WAVE;
@@ -372,7 +396,25 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
     if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
     else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
   };
-  const int myAt = oc_my_chunks<NW>(pl.At.chunk_off, pl.At.nchunks, wid, lane), myA = oc_my_chunks<NW>(pl.A.chunk_off, pl.A.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
+  const int myAt = oc_my_chunks<NW>(TL ? oc.tl.Atr_off : pl.At.chunk_off, pl.At.nchunks, wid, lane), myA = oc_my_chunks<NW>(TL ? oc.tl.Ar_off : pl.A.chunk_off, pl.A.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
+  // TL: this wave's tile records, read once into the lanes of registers (picked out with v_readlane inside the sweeps: no table access in front of a chunk's loads).
+  //   A' sweep, lane 4 k + u: the tile of column block u of the wave's k-th chunk (or the zero tile) and the first of its sixteen rows of w
+  //   A sweep,  lane 8 k + u: the u-th tile with a row in the wave's k-th chunk {tile, column block, first row, rows}; lane k of taCnt: how many; bit k of
+  //             tiled: this lane's row of that chunk gets a tile contribution
+  int ttId = 0, ttFirst = 0, taId = 0, taJ = 0, taFirst = 0, taRows = 0, taCnt = 0, tiled = 0;
+  const double *tiles = nullptr, *valAr = nullptr, *valAtr = nullptr;
+  if constexpr (TL) {
+    const DevTile &tl = oc.tl;
+    tiles = ws + tl.o_tile; valAr = ws + tl.o_ellAr; valAtr = ws + tl.o_ellAtr;
+    const int cT = wid + (lane >> 2) * NW, cA = wid + (lane >> 3) * NW;
+    ttId = cT < pl.At.nchunks ? tl.tt_info[16 * cT + 4 * (lane & 3)] : tl.ntile; ttFirst = cT < pl.At.nchunks ? tl.tt_info[16 * cT + 4 * (lane & 3) + 1] : 0;
+    const bool okA = cA < pl.A.nchunks;
+    taId = okA ? tl.ta_info[32 * cA + 4 * (lane & 7)] : tl.ntile; taJ = okA ? tl.ta_info[32 * cA + 4 * (lane & 7) + 1] : 0;
+    taFirst = okA ? tl.ta_info[32 * cA + 4 * (lane & 7) + 2] : 0; taRows = okA ? tl.ta_info[32 * cA + 4 * (lane & 7) + 3] : 0;
+    taCnt = (lane < 8 && wid + lane * NW < pl.A.nchunks) ? tl.ta_cnt[wid + lane * NW] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int c = wid + k * NW; if (c < pl.A.nchunks) tiled |= (int)((tl.ta_mask[c] >> lane) & 1ull) << k; }
+  }
   // rho_i and 1 / rho_i of a row are selected from the three values the rho rule can produce (no per-row division); they change with rho only
   double rho_in = 0, rho_eq = 0, ri_eq = 0, ri_in = 0; const double ri_min = 1.0 / Q_RHO_MIN;
   auto rho_constants = [&]() { rho_in = opaque_uni(cx.rho); rho_eq = opaque_uni(Q_RHO_EQ * cx.rho); ri_eq = opaque_uni(1.0 / (Q_RHO_EQ * cx.rho)); ri_in = opaque_uni(1.0 / cx.rho); };
@@ -415,8 +457,31 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
         const int t = ch * WAVE + lane;
         const int k = (ch - wid) / NW;
         const double xt = t < npad ? cx.X[t] : 0.0, qt = t < npad ? cx.Q[t] : 0.0;      // (read while the loads fly)
+        if constexpr (TL) {
+          // the four column blocks of the chunk: their tiles read TRANSPOSED (lane (c = l >> 2, j = l & 3) takes entries [4 j .. 4 j + 3][c]: each load instruction
+          // four whole 128-byte lines), requested before the remainder layout's slots; the tile sums reach the variables' rows of R behind the owner's write
+          const int tc = lane >> 2, tj = 4 * (lane & 3);
+          d4 ta[4]; int first[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double *T = tiles + (long)__builtin_amdgcn_readlane(ttId, 4 * k + u) * BLK + tj * BS + tc;
+            ta[u] = d4{T[0], T[BS], T[2 * BS], T[3 * BS]};
+            first[u] = __builtin_amdgcn_readlane(ttFirst, 4 * k + u);
+          }
+          const double v = ell_chunk_g<8>(valAtr, oc.tl.Atr_idx, cx.W, __builtin_amdgcn_readlane(myAt, 2 * k), __builtin_amdgcn_readlane(myAt, 2 * k + 1), lane);
+          if (t < npad) cx.R[t] = v + __builtin_fma(sigma, xt, -qt);
+          double ts[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double *wp = cx.W + first[u] + tj;
+            ts[u] = oc_quad_sum(oc_dot4(ta[u], d4{wp[0], wp[1], wp[2], wp[3]}, 0.0));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if ((lane & 3) == 0 && 4 * ch + u < pl.nb) cx.R[BS * (4 * ch + u) + tc] += ts[u];
+        } else {
         const double v = ell_chunk_g<OCU>(valAt, pl.At.idx, cx.W, __builtin_amdgcn_readlane(myAt, 2 * k), __builtin_amdgcn_readlane(myAt, 2 * k + 1), lane);
         if (t < npad) cx.R[t] = v + __builtin_fma(sigma, xt, -qt);      // (written out: which products the compiler fuses in a * b - c + d depends on the order it meets them in)
+        }
       }
 #endif
       for (int t = tid; t < rs.rext; t += NT) cx.R[npad + t] = 0.0;
@@ -444,7 +509,32 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
           const int i = ch * WAVE + lane, k = (ch - wid) / NW;
           const double lo = lb[i], up = ub[i];
           const double zo = i < mpad ? cx.Z[i] : 0.0, yo = i < mpad ? cx.Y[i] : 0.0;
-          const double zt = ell_chunk_g<OCU>(valA, pl.A.idx, cx.R, __builtin_amdgcn_readlane(myA, 2 * k), __builtin_amdgcn_readlane(myA, 2 * k + 1), lane);
+          double zt;
+          if constexpr (TL) {
+            // the tiles with a row in this chunk, as they lie (one 32-byte row piece per lane), four in flight; a tile sum reaches its row's owner through w,
+            // which is dead until the row update rewrites it (a tile whose rows straddle two chunks is computed for both; each wave keeps its own rows)
+            const int cnt = __builtin_amdgcn_readlane(taCnt, k), tr = lane >> 2, tj = 4 * (lane & 3);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+              if (cnt > 4 * g) {
+                d4 ta[4]; d4 xv[4]; int rid[4]; bool mine[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  const int l8 = 8 * k + 4 * g + u;
+                  ta[u] = reinterpret_cast<const d4 *>(tiles + (long)__builtin_amdgcn_readlane(taId, l8) * BLK)[lane];
+                  const double *xp = cx.R + BS * __builtin_amdgcn_readlane(taJ, l8) + tj;
+                  xv[u] = d4{xp[0], xp[1], xp[2], xp[3]};
+                  rid[u] = __builtin_amdgcn_readlane(taFirst, l8) + tr;
+                  mine[u] = tr < __builtin_amdgcn_readlane(taRows, l8) && (rid[u] >> 6) == ch && (lane & 3) == 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const double sv = oc_quad_sum(oc_dot4(ta[u], xv[u], 0.0)); if (mine[u]) cx.W[rid[u]] = sv; }
+              }
+            }
+            zt = ell_chunk_g<8>(valAr, oc.tl.Ar_idx, cx.R, __builtin_amdgcn_readlane(myA, 2 * k), __builtin_amdgcn_readlane(myA, 2 * k + 1), lane);
+            if ((tiled >> k) & 1) zt += cx.W[i];
+          } else
+          zt = ell_chunk_g<OCU>(valA, pl.A.idx, cx.R, __builtin_amdgcn_readlane(myA, 2 * k), __builtin_amdgcn_readlane(myA, 2 * k + 1), lane);
           if (i < m) {
             const bool loose = lo < -Q_INFTY * Q_MIN_SCALING && up > Q_INFTY * Q_MIN_SCALING, eq = up - lo < Q_RHO_TOL;
             const double rh = loose ? Q_RHO_MIN : (eq ? rho_eq : rho_in), rinv = loose ? ri_min : (eq ? ri_eq : ri_in);

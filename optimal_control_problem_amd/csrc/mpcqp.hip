@@ -73,6 +73,7 @@ struct mpcqp_handle {
   bool split = false;           // ... as two kernels, set-up and iteration (kernel_oc_split.hpp): the default; MPCQP_OC_MONO=1 and the tile experiment keep the single kernel
   OcPlan ocplan; DevOc doc;
   TilePlan tplan; bool tiles = false;   // on-chip kernels: dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan)
+  bool vtiles = false;                  // ... in the two-kernel form, on the vector ALUs (kernel_oc_split.hpp; MPCQP_VTILES=1)
   ResPlan rplan; DevRes dres;
   DevPlan dp; DevIO io;
   std::vector<void *> dev_allocs;
@@ -159,6 +160,7 @@ static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
 static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->oc8 ? 8 : 4, h->ocplan.has_hub != 0, reuse); }
 static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
   const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = !h->ocplan.has_hub ? 0 : h->oc8 ? OC8_INST[h->oc8 - 1].nh : OC_NH;
+  if (h->vtiles && !rf) return mpcqp_kernel_oc_admm_tl(nw, ng, nh);      // (the last launch of a solve, rf, runs the ELL sweeps: the set-up writes both forms)
   return rf ? mpcqp_kernel_oc_admm_rf(nw, ng, nh) : mpcqp_kernel_oc_admm(nw, ng, nh);
 }
 // One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
@@ -357,6 +359,20 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
                    lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg, &h->tplan) <= (h->oc8 ? OC8_LDS_MAX : OC_LDS_MAX);
         if (h->tiles) h->wl = ws_layout(pl, &h->tplan);
       }
+      if (h->oc && !h->tiles && getenv("MPCQP_VTILES") && getenv("MPCQP_VTILES")[0] == '1' && !getenv("MPCQP_OC_MONO")) {
+        // EXPERIMENT, opt-in (MPCQP_VTILES=1): the two sweeps of the iteration on ONE copy of A's dense blocks -- 16 x 16 tiles, row-major in the slab, multiplied
+        // on the vector ALUs (kernel_oc_split.hpp) -- plus the remainder ELL layouts.  No LDS beyond the ELL form's.  The set-up still writes the two ELL copies:
+        // the residual sweeps of the termination checks and the factorisation read them.
+        h->tplan = build_tile_plan(pl, n, m, Ap, Ai, 2);
+        bool fits = h->tplan.on && h->tplan.max_per_block <= 1 && h->tplan.max_per_chunk <= 8 && h->tplan.rows_consecutive &&
+                    pl.A.nchunks <= 8 * want && pl.At.nchunks <= 16 * want;          // (a wave's tile records ride in the lanes of registers: 8 tiles x 8 chunks of A, 4 blocks x 16 chunks of A')
+        for (int t = 0; t < h->tplan.ntile && fits; t++) {
+          int first = -1; for (int r = 0; r < BS; r++) if (h->tplan.rowid[(size_t)t * BS + r] >= 0) { first = h->tplan.rowid[(size_t)t * BS + r]; break; }
+          fits = first >= 0 && first + BS <= pl.mpad;                                 // (a tile's sixteen rows of w are read as they lie: all inside the vector)
+        }
+        h->vtiles = fits;
+        if (h->vtiles) h->wl = ws_layout(pl, &h->tplan);
+      }
       long need = h->oc ? lds_bytes_oc(pl, h->rplan, h->ocplan, h->oc8 && h->zyg, h->tiles ? &h->tplan : nullptr) : h->gblocks ? lds_bytes_res_gb(pl, h->rplan) : lds_bytes_res(pl, h->rplan);
       if (h->oc && !h->tiles && getenv("MPCQP_DOUBLES")) {
         // EXPERIMENT, opt-in (MPCQP_DOUBLES=<n>): double stages of the solve (plan.hpp oc_add_doubles) where the CU's LDS has room for their product blocks
@@ -427,19 +443,26 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
       // (single-kernel four-wave instance only: the eight-wave solve, oc_solve_long, has no ticket wait, and the two-kernel form sweeps all of A' up front)
-      h->split = !h->tiles && !getenv("MPCQP_OC_MONO") && pl.A.nchunks <= 32 * h->variant && pl.At.nchunks <= 32 * h->variant;      // (a wave's chunk offsets ride in the lanes of one register: kernel_oc_split.hpp oc_my_chunks)
+      h->split = !h->tiles && !getenv("MPCQP_OC_MONO") && pl.A.nchunks <= 32 * h->variant && pl.At.nchunks <= 32 * h->variant;
+      if (!h->split || !mpcqp_kernel_oc_admm_tl(h->variant, h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, !o.has_hub ? 0 : h->oc8 ? OC8_INST[h->oc8 - 1].nh : OC_NH)) h->vtiles = false;      // (a wave's chunk offsets ride in the lanes of one register: kernel_oc_split.hpp oc_my_chunks)
       if (const char *e = getenv("MPCQP_RESUME_ROUNDS")) h->resume_rounds = std::max(0, std::min(atoi(e), 8));
       if (getenv("MPCQP_LATE") && !h->tiles && !h->oc8 && !h->split) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
       UP(upload(h, o.tab, &d.tab));
       UP(upload(h, oc_asm_records(pl), &d.asm_rec));
-      if (h->tiles) {
+      if (h->tiles || h->vtiles) {
         const TilePlan &tp = h->tplan; DevTile &t = d.tl;
         t.on = 1; t.ntile = tp.ntile; t.nAr = tp.Ar.nchunks; t.nAtr = tp.Atr.nchunks; t.Ar_entries = tp.Ar.entries(); t.Atr_entries = tp.Atr.entries();
         UP(upload(h, tp.Ar.chunk_off, &t.Ar_off)); UP(upload(h, tp.Ar.idx, &t.Ar_idx)); UP(upload(h, tp.Ar.src, &t.Ar_src));
         UP(upload(h, tp.Atr.chunk_off, &t.Atr_off)); UP(upload(h, tp.Atr.idx, &t.Atr_idx)); UP(upload(h, tp.Atr.src, &t.Atr_src));
-        UP(upload(h, tp.tJ, &t.tJ)); UP(upload(h, tp.rowid, &t.rowid)); UP(upload(h, tp.tsrc, &t.tsrc));
+        UP(upload(h, tp.tJ, &t.tJ)); UP(upload(h, tp.rowid, &t.rowid));
+        if (h->vtiles) {      // row-major tiles for the vector-ALU form: element (r, c) at 16 r + c (the plan keeps the MFMA operand order [r + 16 (c & 3)][c >> 2])
+          std::vector<int> rm(tp.tsrc.size(), -1);
+          for (size_t tt = 0; tt < tp.tsrc.size() / BLK; tt++) for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++)
+            rm[tt * BLK + r * BS + c] = tp.tsrc[tt * BLK + (r + BS * (c & 3)) * 4 + (c >> 2)];
+          UP(upload(h, rm, &t.tsrc));
+        } else UP(upload(h, tp.tsrc, &t.tsrc));
         {   // per-chunk records of fixed size (kernel_onchip.hpp oc_tiles_a / oc_tiles_at): {tile, column block, first row, rows}, padded with the zero tile
           auto first = [&](int tt) { for (int r = 0; r < BS; r++) if (tp.rowid[(size_t)tt * BS + r] >= 0) return tp.rowid[(size_t)tt * BS + r]; return 0; };
           auto rows = [&](int tt) { int k = 0; for (int r = 0; r < BS; r++) k += tp.rowid[(size_t)tt * BS + r] >= 0; return k; };
