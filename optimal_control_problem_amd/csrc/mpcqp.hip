@@ -1056,7 +1056,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *o) {
   if (h->inner) return mpcqp_plan_info(h->inner, o);        // the plan that runs: the reduced pattern's
   const Plan &pl = h->plan;
   o[0] = h->n; o[1] = h->m; o[2] = h->batch; o[3] = pl.npad; o[4] = pl.mpad; o[5] = pl.nb; o[6] = pl.nblk; o[7] = h->lds;
-  o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = h->oc ? (h->tiles ? h->tplan.ntile : 0) : (long)pl.fac.size();
+  o[8] = h->wl.stride * 8; o[9] = pl.ordering; o[10] = pl.nnzP_triu; o[11] = pl.nnzA_in; o[12] = pl.nT; o[13] = h->oc ? ((h->tiles || h->vtiles) ? h->tplan.ntile : 0) : (long)pl.fac.size();
   o[14] = pl.A.slots() + pl.At.slots() + pl.P.slots(); o[15] = h->oc ? 200 + h->variant : h->gblocks ? 100 + h->variant : h->variant;
   return MPCQP_OK;
 }

@@ -997,6 +997,26 @@ def test_two_wave_global_block_kernel_on_a_long_horizon(built, monkeypatch):
         _close(got, ref, k)
 
 
+@pytest.mark.parametrize("name,B,N,eps", [("quadrotor", 12, 20, 1e-3), ("quadrotor", 6, 50, 1e-3), ("quadrotor", 8, 20, 1e-7)])
+def test_experimental_vector_tile_sweeps_vs_oracle(built, monkeypatch, name, B, N, eps):
+    """MPCQP_VTILES=1 (opt-in, experimental, round 4): the two sweeps of the two-kernel form's iteration on ONE row-major copy of A's dense 16 x 16
+    blocks, multiplied on the vector ALUs, + remainder ELL layouts -- same scaled numbers as the ELL arrays, another summation order: same bar as
+    every family.  The tight-tolerance case runs past the adaptive-rho steps: instances leave the tile kernel for a new factor and come back."""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    monkeypatch.setenv("MPCQP_VTILES", "1")
+    mdl, ls, _ = models.make_workload(name, B, N=N)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, eps_abs=eps, eps_rel=eps)
+    info = qp.plan_info()
+    assert info["variant"] in (204, 208) and info["tiles"] == N - 1          # one tile per dynamics stage
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    ref = problems.oracle_solve(ls, eps_abs=eps, eps_rel=eps)
+    assert (got["status"] == ref["status"]).all() and (got["iters"] == ref["iters"]).all()
+    if eps < 1e-3:
+        assert ref["iters"].max() > 100
+    for k in ("x", "y", "z"):
+        _close(got, ref, k)
+
+
 @pytest.mark.parametrize("name,B,N", [("quadrotor", 12, 20), ("quadrotor", 6, 50), ("quadrotor", 5, 30)])
 def test_experimental_tile_sweeps_vs_oracle(built, monkeypatch, name, B, N):
     """MPCQP_TILES=1 (opt-in, experimental): the iteration's two sweeps on dense 16 x 16 tiles of A through the 4-block MFMA + remainder ELL
