@@ -70,6 +70,10 @@ struct mpcqp_handle {
   bool oc = false;              // on-chip mode of the global-block kernel (kernel_onchip.hpp): two workgroups per CU, factor in LDS + registers
   int oc8 = 0;                  // ... its eight-wave instances for long chains (one workgroup per CU): 1 = <NG 4, NH 4>, 2 = <NG 7, NH 7>
   int resume_rounds = 1;        // two-kernel form: {re-factorisation, iteration} pairs queued behind a solve before the last pair (MPCQP_RESUME_ROUNDS)
+  // two-kernel form: the set-up kernel's own launch shape.  Nothing of the factor is resident while it runs, so it does not need the iteration kernel's LDS
+  // (the block slots) or its eight waves: four-wave workgroups (oc_ldl's chain waves and helpers are four in any case) with an LDS request of their own let
+  // two or three QPs share a CU where the iteration kernel has one
+  int setup_nw = 0; long lds_setup = 0; DevRes dres_setup; DevOc doc_setup;
   bool split = false;           // ... as two kernels, set-up and iteration (kernel_oc_split.hpp): the default; MPCQP_OC_MONO=1 and the tile experiment keep the single kernel
   OcPlan ocplan; DevOc doc;
   TilePlan tplan; bool tiles = false;   // on-chip kernels: dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan)
@@ -157,7 +161,7 @@ static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
   return lds(4, h->wide ? 1 : 2);
 }
 // the two kernels of the on-chip mode (kernel_oc_split.hpp): CuCaQP::initSolver and CuCaQP::solve
-static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->oc8 ? 8 : 4, h->ocplan.has_hub != 0, reuse); }
+static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->setup_nw, h->ocplan.has_hub != 0, reuse); }
 static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
   const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = !h->ocplan.has_hub ? 0 : h->oc8 ? OC8_INST[h->oc8 - 1].nh : OC_NH;
   if (h->vtiles && !rf) return mpcqp_kernel_oc_admm_tl(nw, ng, nh);      // (the last launch of a solve, rf, runs the ELL sweeps: the set-up writes both forms)
@@ -167,18 +171,22 @@ static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
 // (kernel_oc_split.hpp: they leave the iteration kernel marked OC_PENDING), `resume_rounds` pairs of {re-factorisation, iteration} in which every other
 // workgroup returns at once, and a last pair whose iteration kernel re-factorises in place, so that any number of rho updates is served.
 static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, hipEvent_t after_setup) {
-  const dim3 grid(count), block(h->variant * WAVE);
+  const dim3 grid(count), block(h->variant * WAVE), block_s(h->setup_nw * WAVE);
   DevOc doc0 = h->doc; doc0.resume = 0;
   DevOc docr = doc0; docr.resume = 1;
+  DevOc docs0 = h->doc_setup; docs0.resume = 0;
+  DevOc docsr = docs0; docsr.resume = 1;
   void *args[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&doc0};
   void *argr[] = {(void *)&h->dp, (void *)&h->dres, (void *)&h->st, (void *)&io, (void *)&docr};
-  HIPCHK(hipLaunchKernel(oc_setup_of(h, reuse), grid, block, args, (size_t)h->lds, s));
+  void *sargs[] = {(void *)&h->dp, (void *)&h->dres_setup, (void *)&h->st, (void *)&io, (void *)&docs0};
+  void *sargr[] = {(void *)&h->dp, (void *)&h->dres_setup, (void *)&h->st, (void *)&io, (void *)&docsr};
+  HIPCHK(hipLaunchKernel(oc_setup_of(h, reuse), grid, block_s, sargs, (size_t)h->lds_setup, s));
   if (after_setup) HIPCHK(hipEventRecord(after_setup, s));
   const bool rho_updates = h->st.adaptive_rho != 0;
   HIPCHK(hipLaunchKernel(oc_admm_of(h, !rho_updates), grid, block, args, (size_t)h->lds, s));     // (without adaptive rho nothing ever leaves: either instance serves)
   if (!rho_updates) return MPCQP_OK;
   for (int r = 0; r <= h->resume_rounds; r++) {
-    HIPCHK(hipLaunchKernel(oc_setup_of(h, false), grid, block, argr, (size_t)h->lds, s));
+    HIPCHK(hipLaunchKernel(oc_setup_of(h, false), grid, block_s, sargr, (size_t)h->lds_setup, s));
     HIPCHK(hipLaunchKernel(oc_admm_of(h, r == h->resume_rounds), grid, block, argr, (size_t)h->lds, s));
   }
   return MPCQP_OK;
@@ -449,6 +457,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       if (getenv("MPCQP_LATE") && !h->tiles && !h->oc8 && !h->split) oc_late_chunks(pl, o, 4, 3 /* OC_POLL_TRIP */, &d.at_poll, &d.at_free);
       d.a_lds = (long)pl.A.entries() <= dr.stage ? 1 : 0;
       d.p_lds = d.a_lds && (long)pl.A.entries() + (long)pl.P.entries() <= dr.stage ? 1 : 0;
+      h->setup_nw = h->variant; h->dres_setup = dr; h->lds_setup = 0;
       UP(upload(h, o.tab, &d.tab));
       UP(upload(h, oc_asm_records(pl), &d.asm_rec));
       if (h->tiles || h->vtiles) {
@@ -491,6 +500,25 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       }
     }
   }
+  if (h->oc) {      // (after the tables are uploaded: the set-up kernel's copies of the arguments)
+    h->doc_setup = h->doc; h->lds_setup = h->lds;
+    if (h->split && !getenv("MPCQP_SETUP8")) {
+      // the set-up as four-wave workgroups with their own LDS request -- the factorisation's scratch blocks and assembly records, or the staged values of A
+      // and P where they fit 80 KB beside the vectors, instead of the iteration kernel's block slots.  Measured (x 8192): cart-pole N=100 set-up kernel 5.61 ->
+      // 4.29 ms (three workgroups per CU instead of one), quadrotor N=30 3.49 -> 2.73, N=10 1.81 -> 1.44 (three instead of two), N=50 8.50 -> 8.29 (two four-wave
+      // workgroups instead of one of eight); N=20 needs 71 KB with its values staged and stays at two (unstaged, at three per CU: 3.26 against 2.68 ms)
+      const Plan &pq = h->plan; DevRes &ds = h->dres_setup; DevOc &dd = h->doc_setup;
+      const long scratch = 8L * BLK + ((4L * pq.nblk + 15) / 16) * 16;                 // (plan.hpp oc_stage_doubles: OC_LDL_SCR blocks + the assembly records)
+      const long vec = 3L * pq.npad + oc_rext(h->variant) + 3L * pq.mpad + 16L * 4 + 16 + 16L * 4 + 64;
+      const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
+      const long cap = (getenv("MPCQP_SETUP_CAP") ? atol(getenv("MPCQP_SETUP_CAP")) : 80 * 1024) / 8;
+      long stage = scratch; dd.a_lds = dd.p_lds = 0;
+      if (std::max(scratch, (long)pq.A.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries()); dd.a_lds = 1; }
+      if (dd.a_lds && std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()); dd.p_lds = 1; }
+      stage = (stage + 15) / 16 * 16;
+      ds.stage = stage; h->setup_nw = 4; h->lds_setup = (stage + vec + tabw) * 8;
+    }
+  }
   const WsLayout &w = h->wl;
   dp.o_ellA = w.ellA; dp.o_ellAt = w.ellAt; dp.o_ellP = w.ellP; dp.o_Lf = w.Lf; dp.o_Lb = w.Lb; dp.o_T = w.T;
   dp.o_l = w.l; dp.o_u = w.u; dp.o_D = w.D; dp.o_E = w.E; dp.o_dx = w.dx; dp.o_dy = w.dy; dp.o_Zg = w.Zg; dp.o_Yg = w.Yg; dp.ws_stride = w.stride;
@@ -514,13 +542,15 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     if (h->variant == 0) fns[0] = fns[1] = h->stream_pd8 ? (const void *)mpcqp_admm_kernel<8> : (const void *)mpcqp_admm_kernel<4>;
     if (h->split) { fns[0] = oc_setup_of(h, false); fns[1] = oc_setup_of(h, true); fns[2] = oc_admm_of(h, false); fns[3] = oc_admm_of(h, true); }
     std::lock_guard<std::mutex> lock(mu);
-    for (const void *fn : fns) {
+    for (int k = 0; k < 4; k++) {
+      const void *fn = fns[k];
       if (!fn) continue;
+      const long want_lds = (h->split && k < 2) ? h->lds_setup : h->lds;
       long &cur = limit[{fn, h->device}];
-      if (h->lds <= cur) continue;
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess)
+      if (want_lds <= cur) continue;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want_lds) != hipSuccess)
         return bail(fail(MPCQP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"));
-      cur = h->lds;
+      cur = want_lds;
     }
   }
   if (h->variant > 0 && !(h->split ? oc_setup_of(h, false) && oc_setup_of(h, true) && oc_admm_of(h, false) && oc_admm_of(h, true) : res_kernel_of(h, false) && res_kernel_of(h, true)))
