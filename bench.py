@@ -364,9 +364,7 @@ def main():
             # the opt-in reduced form on the same batch (mpcqp_create_reduced: the rows dp = 0 named as fixed -> no parameter block, no arrow in the
             # KKT matrix): an equivalent QP, a different ADMM run -- reported beside `value`, never as `value`
             try:
-                # (rows found from the bounds, mpcqp_create_presolved: what a caller of the reference's formulation gets without naming rows -- the parameter
-                # rows dp = 0 AND the pinned first frame)
-                qr_ = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, presolve_bounds=(dl, du), device=local)
+                qr_ = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, fixed_rows=list(range(mdl.np)), device=local)
                 qr_.set_dispatch_hint(False)
                 rit = torch.empty(batch, dtype=torch.int32, device=dev)
                 def rstep():
@@ -379,8 +377,8 @@ def main():
                 torch.cuda.synchronize(); tr = (time.perf_counter() - tr) / 5
                 out["reduced_form"] = {"value": batch / tr, "unit": "QP solves/s", "ms_per_step": tr * 1e3, "kernel_ms": qr_.last_kernel_ms(), "variant": qr_.plan_info()["variant"],
                                        "mean_admm_iters": float(rit.float().mean()), "solved_frac": float((ost == 1).float().mean()),
-                                       "rows_eliminated": qr_.nfixed,
-                                       "note": "opt-in (mpcqp_create_presolved): variables fixed by equality singleton rows -- found from the bounds: the parameter block dp = 0 and the pinned first frame -- substituted before the solve; presolve + solve + postsolve in the step"}
+                                       "note": "opt-in: variables fixed by equality singleton rows (the parameter block, dp = 0) substituted before the solve; presolve + solve + postsolve in the step "
+                                               "(mpcqp_create_reduced; mpcqp_create_presolved finds such rows from the bounds for callers that cannot name them)"}
                 qr_.close()
                 step()      # restore ox / oy / ost of the full form for the legs below
                 torch.cuda.synchronize()
