@@ -34,7 +34,7 @@ __device__ __forceinline__ OcLds<NW> oc_lds(double *lds, const DevPlan &pl, cons
   OcLds<NW> L;
   L.X = lds + rs.stage; L.Q = L.X + pl.npad; L.R = L.Q + pl.npad;
   double *rend = L.R + pl.npad + rs.rext;
-  L.Z = rend; L.Y = L.Z + pl.mpad; L.W = L.Y + pl.mpad;
+  L.Z = rend; L.Y = L.Z + (oc.lay ? oc.zpad : pl.mpad); L.W = L.Y + (oc.lay ? oc.ypad : pl.mpad);
   L.RB = L.W + pl.mpad; L.RED = L.RB + 16 * NW + 16;
   L.octab = reinterpret_cast<int *>(L.RED + 16 * NW) + 8;
   L.co = L.octab + ((oc.o_pos + 1) & ~1);
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     // (the staged values through pointers whose memory the compiler KNOWS: `a_lds ? lds : valA` is a pointer to either, every access through it a
     // flat load that takes both memory paths and waits for both counters -- the whole scaling phase ran on those; one copy of the phase per case)
     const bool a_lds = oc.a_lds, p_lds = oc.p_lds;
-    auto scale_phase = [&](double *sA, double *sP) __attribute__((always_inline)) {
+    auto scale_phase = [&](double *sA, double *sP, auto iA, auto iP) __attribute__((always_inline)) {
     // (eight source indices, then the eight values they point at, in flight at a time: one element per trip was two dependent round trips to memory each)
     auto gather8 = [&](const int *__restrict__ src, const double *__restrict__ in, double *dst, const long entries) __attribute__((always_inline)) {
       long e = tid;
@@ -204,6 +204,9 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     };
     gather8(pl.A.src, inA, sA, pl.A.entries);
     gather8(pl.P.src, inP, sP, pl.P.entries);
+    // (the ten passes gather through these: a read from LDS instead of a round trip to the L2 in front of every batch)
+    if constexpr (sizeof(*iA) == 2) { for (long e = tid; e < pl.A.entries; e += NT) iA[e] = (unsigned short)pl.A.idx[e]; }
+    if constexpr (sizeof(*iP) == 2) { for (long e = tid; e < pl.P.entries; e += NT) iP[e] = (unsigned short)pl.P.idx[e]; }
     for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }
     for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
     bsync<NW>();
@@ -215,18 +218,28 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     // is updated -- and swept once (the second value is the next pass's first; it lives in y, idle here; in the slab when m < n)
     c = 1.0;
     double *nPv = mpad >= npad ? cx.Y : ws + pl.o_dx;
-    if (st.scaling > 0) ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) nPv[t] = x; });
+    if (st.scaling > 0) { for (int ch = wid; ch < pl.P.nchunks; ch += NW) { const int t = ch * WAVE + lane; const double x = ell_chunk_mx(sP, iP, cx.R, cx.coP[ch], cx.coP[ch + 1], lane); if (t < npad) nPv[t] = x; } }
+    // Two barriers per pass: the cost scale's reduction (one max, one sum over the columns of P) is finished by every wave for itself behind the NEXT pass's
+    // first barrier -- the partial results wait in RED meanwhile; c is first needed by the D update.  The chunks of A start at the wave where those of P
+    // end, so that the pair of sweeps between two barriers is balanced.
+    const int shA = pl.P.nchunks % NW;
+    auto cost_scale = [&]() {
+      double r0 = cx.RED[0], r1 = cx.RED[1];
+      for (int w = 1; w < NW; w++) { r0 = fmax(r0, cx.RED[2 * w]); r1 = r1 + cx.RED[2 * w + 1]; }
+      c *= 1.0 / limit_scaling(fmax(r1 / (double)n, limit_scaling(r0)));
+    };
     for (int it = 0; it < st.scaling; it++) {
       RZ_T0;
-      for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
+      for (int ch = (wid + NW - shA) % NW; ch < pl.A.nchunks; ch += NW) {
         const int i = ch * WAVE + lane;
         const double ei = i < mpad ? cx.W[i] : 0.0;
-        const double v = ell_chunk_rc(sA, pl.A.idx, cx.R, ei, cx.X, cx.coA[ch], cx.coA[ch + 1], lane);
+        const double v = ell_chunk_rc(sA, iA, cx.R, ei, cx.X, cx.coA[ch], cx.coA[ch + 1], lane);
         if (i < mpad) cx.W[i] = ei * (1.0 / sqrt(limit_scaling(ei * v)));       // (e_i is read by its own lane only: updated in place)
       }
       RZ_T(4);
       bsync<NW>();
       RZ_T(5);
+      if (it > 0) cost_scale();
       for (int t = tid; t < npad; t += NT) {       // (the thread that wrote nPv[t])
         const double dj = cx.R[t];
         cx.R[t] = dj * (1.0 / sqrt(limit_scaling(fmax(c * dj * nPv[t], dj * cx.X[t]))));
@@ -235,14 +248,20 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       bsync<NW>();
       RZ_T(6);
       double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
-      ell_rowmax_w<NW>(pl.P, cx.coP, sP, cx.R, wid, lane, [&](int t, double x) { if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); } });
+      for (int ch = wid; ch < pl.P.nchunks; ch += NW) {
+        const int t = ch * WAVE + lane;
+#ifdef RZ_OLD_P
+        const double x = ell_chunk<true>(sP, pl.P.idx, cx.R, cx.coP[ch], cx.coP[ch + 1], lane);
+#else
+        const double x = ell_chunk_mx(sP, iP, cx.R, cx.coP[ch], cx.coP[ch + 1], lane);
+#endif
+        if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); }
+      }
+      v[0] = wave_max(v[0]); v[1] = wave_sum(v[1]);
+      if (lane == 0) { cx.RED[2 * wid] = v[0]; cx.RED[2 * wid + 1] = v[1]; }
       RZ_T(7);
-      block_combine<NW, 2, 1>(v, cx.RED, wid, lane);
-      const double ct = 1.0 / limit_scaling(fmax(v[1] / (double)n, limit_scaling(v[0])));
-      c *= ct;
-      bsync<NW>();
-      RZ_T(8);
     }
+    if (st.scaling > 0) { bsync<NW>(); cost_scale(); bsync<NW>(); }
     c = uni(c); cx.c = c; cx.cinv = uni(1.0 / c);
     TS(1);
     // scale and write out: A <- E A D, A' likewise (gathered from the caller's array), P <- c D P D (coalesced stores of whole 512 B slots; up to 8 slots in flight)
@@ -287,9 +306,12 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       ub[i] = i < m ? ei * fmin(inu[i], Q_INFTY) : 0.0;
     }
     };
-    if (a_lds && p_lds) scale_phase(lds, lds + pl.A.entries);
-    else if (a_lds) scale_phase(lds, valP);
-    else scale_phase(valA, valP);
+    unsigned short *i16 = reinterpret_cast<unsigned short *>(L.Z);
+    if (a_lds && p_lds && oc.ix16 == 3) scale_phase(lds, lds + pl.A.entries, i16, i16 + pl.A.entries);
+    else if (a_lds && p_lds && oc.ix16 == 1) scale_phase(lds, lds + pl.A.entries, i16, pl.P.idx);
+    else if (a_lds && p_lds) scale_phase(lds, lds + pl.A.entries, pl.A.idx, pl.P.idx);
+    else if (a_lds) scale_phase(lds, valP, pl.A.idx, pl.P.idx);
+    else scale_phase(valA, valP, pl.A.idx, pl.P.idx);
   }
   for (int t = tid; t < npad; t += NT) Qs[t] = cx.Q[t];         // the scaled q crosses to the iteration kernel through the slab
   bsync<NW>();

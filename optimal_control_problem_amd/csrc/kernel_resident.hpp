@@ -136,8 +136,8 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // (Every lane walks its row's slots in its own rotation, slot (u + lane) mod width in step u: the rows of one stage share their columns slot by
 // slot, and same-address LDS atomics of one instruction serialise -- 12 rows of a stage hitting one column cost the sweep half its time.  A maximum
 // does not care about the order.)
-template <int U>
-__device__ __forceinline__ double ell_batch_rc(const double *__restrict__ val, const int *__restrict__ idx, const double *din, const double ei, double *colacc,
+template <int U, class IT>
+__device__ __forceinline__ double ell_batch_rc(const double *__restrict__ val, const IT *__restrict__ idx, const double *din, const double ei, double *colacc,
                                                const long e0, const int u0, const int r0, const int w, double acc) {
   double v[U]; int ix[U];
 #pragma unroll
@@ -145,15 +145,21 @@ __device__ __forceinline__ double ell_batch_rc(const double *__restrict__ val, c
     int su = u0 + u + r0; su -= su >= w ? w : 0;
     const long e = e0 + (long)su * WAVE;
     v[u] = fabs(val[e]); ix[u] = idx[e];
+#ifdef RZ_FAKEIDX
+    ix[u] = (int)((e * 5) & 255);
+#endif
   }
 #pragma unroll
   for (int u = 0; u < U; u++) {
     acc = fmax(acc, v[u] * din[ix[u]]);
+#ifndef RZ_NOATOM
     if (v[u] != 0.0) __hip_atomic_fetch_max((lds_u64 *)(colacc + ix[u]), (unsigned long long)__double_as_longlong(v[u] * ei), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
   }
   return acc;
 }
-__device__ __forceinline__ double ell_chunk_rc(const double *__restrict__ val, const int *__restrict__ idx, const double *din, const double ei, double *colacc, const int s0, const int s1, const int lane) {
+template <class IT>
+__device__ __forceinline__ double ell_chunk_rc(const double *__restrict__ val, const IT *__restrict__ idx, const double *din, const double ei, double *colacc, const int s0, const int s1, const int lane) {
   const int w = s1 - s0;
   if (w <= 0) return 0.0;
   const long e0 = (long)s0 * WAVE + lane;
@@ -164,6 +170,33 @@ __device__ __forceinline__ double ell_chunk_rc(const double *__restrict__ val, c
   if ((w - u0) & 4) { acc = ell_batch_rc<4>(val, idx, din, ei, colacc, e0, u0, r0, w, acc); u0 += 4; }
   if ((w - u0) & 2) { acc = ell_batch_rc<2>(val, idx, din, ei, colacc, e0, u0, r0, w, acc); u0 += 2; }
   if ((w - u0) & 1) acc = ell_batch_rc<1>(val, idx, din, ei, colacc, e0, u0, r0, w, acc);
+  return acc;
+}
+// max_s |val| * in[idx] of one chunk with the gathers of a batch in flight together (a maximum does not care about the order); the index array may be
+// a 16-bit table in LDS
+template <int U, class IT>
+__device__ __forceinline__ double ell_batch_mx(const double *__restrict__ &vp, const IT *__restrict__ &ip, const double *in, double acc) {
+  double v[U], x[U]; int ix[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { v[u] = vp[u * WAVE]; ix[u] = ip[u * WAVE]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) x[u] = in[ix[u]];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < U; u++) acc = fmax(acc, fabs(v[u]) * x[u]);
+  vp += U * WAVE; ip += U * WAVE;
+  return acc;
+}
+template <class IT>
+__device__ __forceinline__ double ell_chunk_mx(const double *__restrict__ val, const IT *__restrict__ idx, const double *in, const int s0, const int s1, const int lane) {
+  const double *__restrict__ vp = val + ((long)s0 * WAVE + lane);
+  const IT *__restrict__ ip = idx + ((long)s0 * WAVE + lane);
+  double acc = 0.0;
+  int rem = s1 - s0;
+  for (; rem >= 8; rem -= 8) acc = ell_batch_mx<8>(vp, ip, in, acc);
+  if (rem & 4) acc = ell_batch_mx<4>(vp, ip, in, acc);
+  if (rem & 2) acc = ell_batch_mx<2>(vp, ip, in, acc);
+  if (rem & 1) acc = ell_batch_mx<1>(vp, ip, in, acc);
   return acc;
 }
 // out[e] = f(value, index) over the slots of one chunk, 8 / 4 / 2 / 1 slots per batch with all loads of a batch issued before the first use.

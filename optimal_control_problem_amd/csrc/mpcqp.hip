@@ -509,14 +509,28 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // workgroups instead of one of eight); N=20 needs 71 KB with its values staged and stays at two (unstaged, at three per CU: 3.26 against 2.68 ms)
       const Plan &pq = h->plan; DevRes &ds = h->dres_setup; DevOc &dd = h->doc_setup;
       const long scratch = 8L * BLK + ((4L * pq.nblk + 15) / 16) * 16;                 // (plan.hpp oc_stage_doubles: OC_LDL_SCR blocks + the assembly records)
-      const long vec = 3L * pq.npad + oc_rext(h->variant) + 3L * pq.mpad + 16L * 4 + 16 + 16L * 4 + 64;
+      // (its own vector layout: z is never touched and y holds one n-vector of the Ruiz passes, kernel_oc_split.hpp oc_lds)
+      dd.lay = 1; dd.ix16 = 0; dd.zpad = 0; dd.ypad = pq.mpad >= pq.npad ? pq.npad : 0;
+      const long vec = 3L * pq.npad + oc_rext(h->variant) + pq.mpad + dd.ypad + 16L * 4 + 16 + 16L * 4 + 64;
       const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
       const long cap = (getenv("MPCQP_SETUP_CAP") ? atol(getenv("MPCQP_SETUP_CAP")) : 80 * 1024) / 8;
       long stage = scratch; dd.a_lds = dd.p_lds = 0;
       if (std::max(scratch, (long)pq.A.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries()); dd.a_lds = 1; }
       if (dd.a_lds && std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()); dd.p_lds = 1; }
       stage = (stage + 15) / 16 * 16;
-      ds.stage = stage; h->setup_nw = 4; h->lds_setup = (stage + vec + tabw) * 8;
+      // with both value arrays staged, the index arrays of A (and P) as 16-bit tables in the z region where that does not cost a workgroup per CU: the ten
+      // Ruiz passes then gather without a round trip to the L2 in front of every batch
+      long vecs = vec;
+      if (dd.a_lds && dd.p_lds && pq.npad < 65536 && !getenv("MPCQP_NO_IX16")) {
+        const long zA = ((long)pq.A.entries() / 4 + 15) / 16 * 16, zAP = (((long)pq.A.entries() + (long)pq.P.entries()) / 4 + 15) / 16 * 16;
+        const long base = (stage + vecs + tabw) * 8, cu = 160L * 1024;
+        if (base + zAP * 8 <= cap * 8 && cu / (base + zAP * 8) == cu / base) { dd.ix16 = 3; dd.zpad = (int)zAP; }
+        else if (base + zA * 8 <= cap * 8 && cu / (base + zA * 8) == cu / base) { dd.ix16 = 1; dd.zpad = (int)zA; }
+        vecs += dd.zpad;
+      }
+      ds.stage = stage; h->setup_nw = 4; h->lds_setup = (stage + vecs + tabw) * 8;
+      if (getenv("MPCQP_VERBOSE")) fprintf(stderr, "mpcqp: set-up kernel shape: 4 waves, %ld B of LDS (values of A %s, of P %s, 16-bit index tables %s; A %ld + P %ld entries, vectors %ld, tables %ld doubles), iteration kernel %ld B\n",
+                                           h->lds_setup, dd.a_lds ? "staged" : "in the slab", dd.p_lds ? "staged" : "in the slab", dd.ix16 == 3 ? "A and P" : dd.ix16 ? "A" : "off", (long)pq.A.entries(), (long)pq.P.entries(), vecs, tabw, (long)h->lds);
     }
   }
   const WsLayout &w = h->wl;
