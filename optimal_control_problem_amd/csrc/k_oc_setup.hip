@@ -5,7 +5,5 @@ MPCQP_HIDDEN const void *mpcqp_kernel_oc_setup(int nw, bool hub, bool reuse) {
     if (hub) return reuse ? (const void *)mpcqp_oc_setup_kernel<4, true, true> : (const void *)mpcqp_oc_setup_kernel<4, false, true>;
     return reuse ? (const void *)mpcqp_oc_setup_kernel<4, true, false> : (const void *)mpcqp_oc_setup_kernel<4, false, false>;
   }
-  if (nw == 8 && hub) return reuse ? (const void *)mpcqp_oc_setup_kernel<8, true, true> : (const void *)mpcqp_oc_setup_kernel<8, false, true>;
-  if (nw == 8) return reuse ? (const void *)mpcqp_oc_setup_kernel<8, true, false> : (const void *)mpcqp_oc_setup_kernel<8, false, false>;     // (no arrow head: the reduced form's long chains)
   return nullptr;
 }

@@ -29,12 +29,14 @@ struct OcLds {
   double *X, *Q, *R, *Z, *Y, *W, *RB, *RED;
   int *octab, *co;
 };
-template <int NW>
+template <int NW, bool SETUP = false>
 __device__ __forceinline__ OcLds<NW> oc_lds(double *lds, const DevPlan &pl, const DevRes &rs, const DevOc &oc) {
   OcLds<NW> L;
   L.X = lds + rs.stage; L.Q = L.X + pl.npad; L.R = L.Q + pl.npad;
   double *rend = L.R + pl.npad + rs.rext;
-  L.Z = rend; L.Y = L.Z + (oc.lay ? oc.zpad : pl.mpad); L.W = L.Y + (oc.lay ? oc.ypad : pl.mpad);
+  // (SETUP: the set-up kernel's own vector layout -- it never touches z, whose region holds its 16-bit index tables and is oc.zpad doubles long, and keeps
+  // one n-vector of the Ruiz passes in y)
+  L.Z = rend; L.Y = L.Z + (SETUP ? oc.zpad : pl.mpad); L.W = L.Y + (SETUP ? pl.npad : pl.mpad);
   L.RB = L.W + pl.mpad; L.RED = L.RB + 16 * NW + 16;
   L.octab = reinterpret_cast<int *>(L.RED + 16 * NW) + 8;
   L.co = L.octab + ((oc.o_pos + 1) & ~1);
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
   int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
   const int tid = wid * WAVE + lane;
-  const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
+  const OcLds<NW> L = oc_lds<NW, true>(lds, pl, rs, oc);
   RCtx cx;
   cx.pl = &pl; cx.rs = &rs; cx.st = &st; cx.wid = wid; cx.lane = lane;
   cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
@@ -215,9 +217,9 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     TS(0);
     // ---- modified Ruiz equilibration: D in R, E in W; X = the column-norm accumulators of the sweep over A (one sweep by rows gives the row norm,
     // lane-local, and the column norms, LDS atomic max on the bit pattern); nP = max_k |P_tk| d_k is needed twice per pass -- before and after D
-    // is updated -- and swept once (the second value is the next pass's first; it lives in y, idle here; in the slab when m < n)
+    // is updated -- and swept once (the second value is the next pass's first; it lives in the y region, n doubles long in this kernel)
     c = 1.0;
-    double *nPv = mpad >= npad ? cx.Y : ws + pl.o_dx;
+    double *nPv = cx.Y;
     if (st.scaling > 0) { for (int ch = wid; ch < pl.P.nchunks; ch += NW) { const int t = ch * WAVE + lane; const double x = ell_chunk_mx(sP, iP, cx.R, cx.coP[ch], cx.coP[ch + 1], lane); if (t < npad) nPv[t] = x; } }
     // Two barriers per pass: the cost scale's reduction (one max, one sum over the columns of P) is finished by every wave for itself behind the NEXT pass's
     // first barrier -- the partial results wait in RED meanwhile; c is first needed by the D update.  The chunks of A start at the wave where those of P
@@ -250,11 +252,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       double v[2] = {0.0, 0.0};   // 0 qn (max) 1 sum
       for (int ch = wid; ch < pl.P.nchunks; ch += NW) {
         const int t = ch * WAVE + lane;
-#ifdef RZ_OLD_P
-        const double x = ell_chunk<true>(sP, pl.P.idx, cx.R, cx.coP[ch], cx.coP[ch + 1], lane);
-#else
         const double x = ell_chunk_mx(sP, iP, cx.R, cx.coP[ch], cx.coP[ch + 1], lane);
-#endif
         if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); }
       }
       v[0] = wave_max(v[0]); v[1] = wave_sum(v[1]);

@@ -39,8 +39,7 @@ struct DevOc {
   DevTile tl;           // (the instances without tiles keep their argument layout)
   const void *cold;     // two-kernel form: the kernel arguments once more in global memory (kernel_oc_split.hpp OcCold), for the out-of-line re-factorisation
   int resume;           // two-kernel form: this launch continues instances that left the iteration kernel for a re-factorisation (kernel_oc_split.hpp)
-  int lay, ix16, zpad, ypad;   // lay: the set-up kernel's own LDS layout -- the z region is zpad doubles (the set-up never touches z: it holds the 16-bit index tables of A (ix16 & 1)
-                        // and P (ix16 & 2) instead), the y region ypad (the Ruiz passes keep one n-vector there)
+  int ix16, zpad;       // set-up kernel (its own vector layout, kernel_oc_split.hpp oc_lds): 16-bit index tables of A (& 1) and P (& 2) in its z region of zpad doubles
 };
 
 // LDS image of a 16x16 block: rows alternate between the two 32-bank halves in a pattern that also separates rows 4 apart, the four

@@ -145,16 +145,11 @@ __device__ __forceinline__ double ell_batch_rc(const double *__restrict__ val, c
     int su = u0 + u + r0; su -= su >= w ? w : 0;
     const long e = e0 + (long)su * WAVE;
     v[u] = fabs(val[e]); ix[u] = idx[e];
-#ifdef RZ_FAKEIDX
-    ix[u] = (int)((e * 5) & 255);
-#endif
   }
 #pragma unroll
   for (int u = 0; u < U; u++) {
     acc = fmax(acc, v[u] * din[ix[u]]);
-#ifndef RZ_NOATOM
     if (v[u] != 0.0) __hip_atomic_fetch_max((lds_u64 *)(colacc + ix[u]), (unsigned long long)__double_as_longlong(v[u] * ei), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
   }
   return acc;
 }

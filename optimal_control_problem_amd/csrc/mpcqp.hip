@@ -502,28 +502,27 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   if (h->oc) {      // (after the tables are uploaded: the set-up kernel's copies of the arguments)
     h->doc_setup = h->doc; h->lds_setup = h->lds;
-    if (h->split && !getenv("MPCQP_SETUP8")) {
+    if (h->split) {
       // the set-up as four-wave workgroups with their own LDS request -- the factorisation's scratch blocks and assembly records, or the staged values of A
-      // and P where they fit 80 KB beside the vectors, instead of the iteration kernel's block slots.  Measured (x 8192): cart-pole N=100 set-up kernel 5.61 ->
-      // 4.29 ms (three workgroups per CU instead of one), quadrotor N=30 3.49 -> 2.73, N=10 1.81 -> 1.44 (three instead of two), N=50 8.50 -> 8.29 (two four-wave
-      // workgroups instead of one of eight); N=20 needs 71 KB with its values staged and stays at two (unstaged, at three per CU: 3.26 against 2.68 ms)
+      // and P where they fit 80 KB beside the vectors, instead of the iteration kernel's block slots -- and their own vector layout: z is never touched and
+      // y holds one n-vector of the Ruiz passes (kernel_oc_split.hpp oc_lds).  Measured (x 8192): cart-pole N=100 set-up kernel 5.61 -> 4.29 ms,
+      // quadrotor N=30 3.49 -> 2.73, N=10 1.81 -> 1.44, N=50 8.50 -> 8.29 (two four-wave workgroups instead of one of eight)
       const Plan &pq = h->plan; DevRes &ds = h->dres_setup; DevOc &dd = h->doc_setup;
       const long scratch = 8L * BLK + ((4L * pq.nblk + 15) / 16) * 16;                 // (plan.hpp oc_stage_doubles: OC_LDL_SCR blocks + the assembly records)
-      // (its own vector layout: z is never touched and y holds one n-vector of the Ruiz passes, kernel_oc_split.hpp oc_lds)
-      dd.lay = 1; dd.ix16 = 0; dd.zpad = 0; dd.ypad = pq.mpad >= pq.npad ? pq.npad : 0;
-      const long vec = 3L * pq.npad + oc_rext(h->variant) + pq.mpad + dd.ypad + 16L * 4 + 16 + 16L * 4 + 64;
+      dd.ix16 = 0; dd.zpad = 0;
+      const long vec = 3L * pq.npad + oc_rext(h->variant) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4 + 64;
       const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
-      const long cap = (getenv("MPCQP_SETUP_CAP") ? atol(getenv("MPCQP_SETUP_CAP")) : 80 * 1024) / 8;
+      const long cap = (getenv("MPCQP_SETUP_CAP") ? atol(getenv("MPCQP_SETUP_CAP")) : 80 * 1024) / 8, cu = 160L * 1024;
       long stage = scratch; dd.a_lds = dd.p_lds = 0;
       if (std::max(scratch, (long)pq.A.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries()); dd.a_lds = 1; }
       if (dd.a_lds && std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()); dd.p_lds = 1; }
       stage = (stage + 15) / 16 * 16;
-      // with both value arrays staged, the index arrays of A (and P) as 16-bit tables in the z region where that does not cost a workgroup per CU: the ten
-      // Ruiz passes then gather without a round trip to the L2 in front of every batch
       long vecs = vec;
       if (dd.a_lds && dd.p_lds && pq.npad < 65536 && !getenv("MPCQP_NO_IX16")) {
+        // with both value arrays staged, the index arrays of A (and P) as 16-bit tables in the z region where that does not cost a workgroup per CU: the ten
+        // Ruiz passes then gather without a round trip to the L2 in front of every batch
         const long zA = ((long)pq.A.entries() / 4 + 15) / 16 * 16, zAP = (((long)pq.A.entries() + (long)pq.P.entries()) / 4 + 15) / 16 * 16;
-        const long base = (stage + vecs + tabw) * 8, cu = 160L * 1024;
+        const long base = (stage + vecs + tabw) * 8;
         if (base + zAP * 8 <= cap * 8 && cu / (base + zAP * 8) == cu / base) { dd.ix16 = 3; dd.zpad = (int)zAP; }
         else if (base + zA * 8 <= cap * 8 && cu / (base + zA * 8) == cu / base) { dd.ix16 = 1; dd.zpad = (int)zA; }
         vecs += dd.zpad;

@@ -26,7 +26,7 @@ _lib.check(L.mpcqp_debug_timing(qp._h, raw.ctypes.data))
 m = out.mean(axis=0)
 print("%s N=%s x %d, variant %d: set-up phases, cycles per QP (shader clock)" % (name, horizon, batch, qp.plan_info()["variant"]))
 print("  load %.0f, Ruiz %.0f, scale + write %.0f, factorisation %.0f" % (m[0], m[1], m[2], m[3]))
-names = ["sweep over A (row norms, column atomics)", "barrier behind it", "D update", "sweep over P + cost terms", "reduction + c"]
+names = ["sweep over A (row norms, column atomics)", "barrier behind it", "cost scale + D update", "sweep over P + cost terms (no barrier behind it)"]
 for k, nm in enumerate(names):
     print("  Ruiz, 10 passes: %-45s %8.0f  (%.0f per pass)" % (nm, m[9 + k], m[9 + k] / 10))
 print("  set-up %.3f ms, iteration %.3f ms" % qp.last_phase_ms())
