@@ -338,16 +338,12 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
 // =========================================================================================================
 // RF = 1: an adaptive-rho step re-factorises in place (the last launch of a solve); RF = 0: the instance leaves for the set-up kernel's resume mode
 // TL: the two sweeps of the iteration on dense tiles of A + remainder ELL layouts (experiment; below)
-template <int NW, int OCG, int OCH, int RF, bool TL = false>
-__global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+// One instance; called once per workgroup (a grid of `count` workgroups) or, with DevIO.queue set, again and again by a resident workgroup that draws tickets.
+template <int NW, int OCG, int OCH, int RF, bool TL>
+__device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs, const mpcqp_settings &st, const DevIO &io, const DevOc &oc, double *lds, const int b, const int wid, const int lane) {
   constexpr int NT = NW * WAVE;
   [[maybe_unused]] constexpr int OCU = NW == 4 ? 16 : 8;      // ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
   constexpr bool HUB = OCH > 0;
-  const int lane = threadIdx.x & 63;
-  const int b = __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x);
-  int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
   const int tid = wid * WAVE + lane;
   const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
   RCtx cx;
@@ -642,4 +638,34 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
   ts_acc[12] += cx.fts[0]; ts_acc[13] += cx.fts[1]; ts_acc[14] += cx.fts[2]; ts_acc[15] += cx.fts[3];
 #endif
   TS_STORE_ADD(io.dbg, 0, 16);
+}
+// The launch.  Workgroups are handed to the XCDs and their shader engines round-robin, statically: a grid of one workgroup per instance is 8 x 4 separate
+// queues, and instances whose iteration counts differ (25, 50, 75 ...) leave some of them busy long after the others have drained -- on quadrotor N=50 x 8192
+// the iteration kernel took 23.5 ms in batch order and 21.0 ms with the longest-first order of a repeated solve.  With DevIO.queue the grid is as many
+// workgroups as the GPU holds at once, and each draws the next instance from ONE counter until none is left: the same batch order, balanced to within one
+// instance.  (Every wave reaches the exit: the ticket is read behind a barrier, uniformly.)
+template <int NW, int OCG, int OCH, int RF, bool TL = false>
+__global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63;
+  int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
+  if constexpr (NW != 8) {      // (the four-wave instances, two workgroups per CU, keep a grid of one workgroup per instance: measured below)
+    oc_admm_one<NW, OCG, OCH, RF, TL>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x), wid, lane);
+    return;
+  }
+  const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
+  int *ticket = reinterpret_cast<int *>(L.RED + 16 * NW);      // (the spare words in front of the chain tables)
+  for (;;) {
+    if (threadIdx.x == 0) *ticket = atomicAdd(io.queue, 1);
+    bsync<NW>();
+    const int t = __builtin_amdgcn_readfirstlane(*ticket);
+    if (t >= io.count) break;
+    // (lane and wave index made opaque per instance: everything derived from them is computed again for each instance, as in a fresh workgroup -- hoisted out of
+    // this loop it stays live across the whole body: 240 B of scratch in an instance that had none)
+    int lane_q = lane, wid_q = wid;
+    asm volatile("" : "+v"(lane_q), "+s"(wid_q));
+    oc_admm_one<NW, OCG, OCH, RF, TL>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[t] : t), wid_q, lane_q);
+    bsync<NW>();      // (LDS is this instance's until every wave is through with it -- and the ticket until every wave has read it)
+  }
 }

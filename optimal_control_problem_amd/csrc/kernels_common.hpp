@@ -32,6 +32,7 @@ struct DevIO {
   int reuse, keep;     // kept workspace: skip scaling + factorisation (mpcqp_update_vectors) / store the factor for that
   int no_touch;        // on-chip mode, experiment switch (MPCQP_NO_TOUCH): no L2 prefetch by the idle waves
   int no_remap;        // on-chip mode, experiment switch (MPCQP_NO_REMAP): waves keep the parts their index gives them
+  int *queue; int count;   // two-kernel on-chip mode: resident workgroups draw instance tickets 0 .. count - 1 from *queue (kernel_oc_split.hpp); NULL = one workgroup per instance
 };
 
 // ------------------------------------------------------------------------------------------ device helpers

@@ -74,6 +74,7 @@ struct mpcqp_handle {
   // (the block slots) or its eight waves: four-wave workgroups (oc_ldl's chain waves and helpers are four in any case) with an LDS request of their own let
   // two or three QPs share a CU where the iteration kernel has one
   int setup_nw = 0; long lds_setup = 0; DevRes dres_setup; DevOc doc_setup;
+  int *qctr = nullptr; int qslots = 0;        // two-kernel on-chip mode: ticket counters of the resident iteration workgroups (16 per solve in flight), and how many workgroups the GPU holds at once
   bool split = false;           // ... as two kernels, set-up and iteration (kernel_oc_split.hpp): the default; MPCQP_OC_MONO=1 and the tile experiment keep the single kernel
   OcPlan ocplan; DevOc doc;
   TilePlan tplan; bool tiles = false;   // on-chip kernels: dense tiles of A for the two sweeps of the iteration (plan.hpp build_tile_plan)
@@ -170,8 +171,16 @@ static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
 // One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
 // (kernel_oc_split.hpp: they leave the iteration kernel marked OC_PENDING), `resume_rounds` pairs of {re-factorisation, iteration} in which every other
 // workgroup returns at once, and a last pair whose iteration kernel re-factorises in place, so that any number of rho updates is served.
-static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, hipEvent_t after_setup) {
+static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, hipEvent_t after_setup, int qslot) {
   const dim3 grid(count), block(h->variant * WAVE), block_s(h->setup_nw * WAVE);
+  // the iteration kernel as resident workgroups that draw instances from one counter (kernel_oc_split.hpp) when the batch is more than the GPU holds at once
+  const bool queued = h->oc8 != 0;      // (the eight-wave instances are compiled as resident workgroups; the four-wave ones are not)
+  int *qc = queued ? h->qctr + 16 * qslot : nullptr;
+  if (queued) HIPCHK(hipMemsetAsync(qc, 0, 16 * sizeof(int), s));
+  const dim3 grid_it(queued ? std::min(h->qslots, count) : count);
+  int nlaunch = 0;
+  DevIO ioq[10];
+  auto io_of = [&]() -> void * { DevIO &q = ioq[nlaunch]; q = io; q.queue = queued ? qc + nlaunch : nullptr; q.count = count; return (void *)&ioq[nlaunch++]; };
   DevOc doc0 = h->doc; doc0.resume = 0;
   DevOc docr = doc0; docr.resume = 1;
   DevOc docs0 = h->doc_setup; docs0.resume = 0;
@@ -183,11 +192,13 @@ static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hi
   HIPCHK(hipLaunchKernel(oc_setup_of(h, reuse), grid, block_s, sargs, (size_t)h->lds_setup, s));
   if (after_setup) HIPCHK(hipEventRecord(after_setup, s));
   const bool rho_updates = h->st.adaptive_rho != 0;
-  HIPCHK(hipLaunchKernel(oc_admm_of(h, !rho_updates), grid, block, args, (size_t)h->lds, s));     // (without adaptive rho nothing ever leaves: either instance serves)
+  args[3] = io_of();
+  HIPCHK(hipLaunchKernel(oc_admm_of(h, !rho_updates), grid_it, block, args, (size_t)h->lds, s));     // (without adaptive rho nothing ever leaves: either instance serves)
   if (!rho_updates) return MPCQP_OK;
   for (int r = 0; r <= h->resume_rounds; r++) {
     HIPCHK(hipLaunchKernel(oc_setup_of(h, false), grid, block_s, sargr, (size_t)h->lds_setup, s));
-    HIPCHK(hipLaunchKernel(oc_admm_of(h, r == h->resume_rounds), grid, block, argr, (size_t)h->lds, s));
+    argr[3] = io_of();
+    HIPCHK(hipLaunchKernel(oc_admm_of(h, r == h->resume_rounds), grid_it, block, argr, (size_t)h->lds, s));
   }
   return MPCQP_OK;
 }
@@ -528,8 +539,15 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
         vecs += dd.zpad;
       }
       ds.stage = stage; h->setup_nw = 4; h->lds_setup = (stage + vecs + tabw) * 8;
-      if (getenv("MPCQP_VERBOSE")) fprintf(stderr, "mpcqp: set-up kernel shape: 4 waves, %ld B of LDS (values of A %s, of P %s, 16-bit index tables %s; A %ld + P %ld entries, vectors %ld, tables %ld doubles), iteration kernel %ld B\n",
-                                           h->lds_setup, dd.a_lds ? "staged" : "in the slab", dd.p_lds ? "staged" : "in the slab", dd.ix16 == 3 ? "A and P" : dd.ix16 ? "A" : "off", (long)pq.A.entries(), (long)pq.P.entries(), vecs, tabw, (long)h->lds);
+      if (h->oc8) {
+        int nb = 0; h->qslots = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, oc_admm_of(h, false), h->variant * WAVE, (size_t)h->lds) == hipSuccess && nb > 0) {
+          h->qslots = nb * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        } else (void)hipGetLastError();
+        UP(dalloc(h, &h->qctr, 16 * 16));
+      }
+      if (getenv("MPCQP_VERBOSE")) fprintf(stderr, "mpcqp: set-up kernel shape: 4 waves, %ld B of LDS (values of A %s, of P %s, 16-bit index tables %s; A %ld + P %ld entries, vectors %ld, tables %ld doubles), iteration kernel %ld B, %d resident workgroups\n",
+                                           h->lds_setup, dd.a_lds ? "staged" : "in the slab", dd.p_lds ? "staged" : "in the slab", dd.ix16 == 3 ? "A and P" : dd.ix16 ? "A" : "off", (long)pq.A.entries(), (long)pq.P.entries(), vecs, tabw, (long)h->lds, h->qslots);
     }
   }
   const WsLayout &w = h->wl;
@@ -912,7 +930,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
   HIPCHK(hipEventRecord(h->ev0, s));
   if (h->variant > 0 && h->split) {     // CuCaQP::initSolver, then CuCaQP::solve
-    int rc = launch_oc_split(h, io, h->batch, io.reuse != 0, s, h->ev_mid);
+    int rc = launch_oc_split(h, io, h->batch, io.reuse != 0, s, h->ev_mid, 0);
     if (rc) return rc;
   }
   else if (h->variant > 0) {
@@ -940,7 +958,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
 }
 
 // launch of instances [b0, b0 + count) on stream s: every per-instance pointer of `io` is advanced, the kernels index by blockIdx
-static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_t s) {
+static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_t s, int qslot) {
   const long n = h->n, m = h->m;
   io.P += (long)b0 * io.sP; io.q += (long)b0 * io.sq; io.A += (long)b0 * io.sA; io.l += (long)b0 * io.sl; io.u += (long)b0 * io.su;
   if (io.x0) io.x0 += b0 * n;
@@ -951,7 +969,7 @@ static int launch_slice(mpcqp_handle *h, DevIO io, int b0, int count, hipStream_
   if (io.dbg) io.dbg += 16L * b0;
   io.order = nullptr;
   if (h->variant > 0 && h->split) {
-    int rc = launch_oc_split(h, io, count, false, s, nullptr);
+    int rc = launch_oc_split(h, io, count, false, s, nullptr, qslot);
     if (rc) return rc;
   }
   else if (h->variant > 0) {
@@ -1017,7 +1035,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
     }
     HIPCHK(hipEventRecord(h->pipe_ev[c], cs));
     HIPCHK(hipStreamWaitEvent(s, h->pipe_ev[c], 0));
-    if ((rc = launch_slice(h, io, b0, cnt, s))) return rc;
+    if ((rc = launch_slice(h, io, b0, cnt, s, 1 + c % 15))) return rc;
     if (x) HIPCHK(hipMemcpyAsync(x + (size_t)b0 * n, h->ox + (size_t)b0 * n, (size_t)cnt * n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (y && m) HIPCHK(hipMemcpyAsync(y + (size_t)b0 * m, h->oy + (size_t)b0 * m, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, s));
     if (status) HIPCHK(hipMemcpyAsync(status + b0, h->ostatus + b0, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));

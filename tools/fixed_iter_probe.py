@@ -15,7 +15,7 @@ from optimal_control_problem_amd import _lib, models
 from optimal_control_problem_amd.batch_qp import BatchQP
 
 mdl, ls, _ = models.make_workload(name, batch, N=horizon)
-st = _lib.default_settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, eps_prim_inf=0.0, eps_dual_inf=0.0, adaptive_rho=0)
+st = _lib.default_settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, eps_prim_inf=0.0, eps_dual_inf=0.0, adaptive_rho=0, check_termination=0)
 qp = BatchQP(ls.n, ls.m, batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai, settings=st)
 qp.update(ls.P, ls.q, ls.A, ls.l, ls.u)
 best = None
