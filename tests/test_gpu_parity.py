@@ -662,6 +662,29 @@ def test_pipelined_host_step(built):
     qd.close()
 
 
+def test_resident_workgroups_draw_every_instance_once(built, monkeypatch):
+    """the eight-wave on-chip instances iterate as resident workgroups that draw instance tickets from one counter (kernel_oc_split.hpp): a batch larger than
+    the GPU holds at once, a batch smaller, the pipelined host step's slices (each with its own counter) and a dispatch order all give the results of one
+    workgroup per instance -- the single-kernel form of the same build -- bit for bit"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("cartpole", 700, N=100)
+    monkeypatch.setenv("MPCQP_VARIANT", "oc8")
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert qp.plan_info()["variant"] == 208
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); ref = qp.get()
+    qp.solve(); hinted = qp.get()                                                   # second solve: longest-first order of the tickets
+    host = qp.solve_host(ls.P, ls.q, ls.A, ls.l, ls.u, chunks=5)                    # 140 instances per slice: fewer than resident workgroups
+    qp.close()
+    monkeypatch.setenv("MPCQP_OC_MONO", "1")
+    q1 = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    q1.update(ls.P, ls.q, ls.A, ls.l, ls.u); q1.solve(); mono = q1.get(); q1.close()
+    assert (ref["status"] == 1).all() and len(np.unique(ref["iters"])) > 2           # (iteration counts differ: what the queue is for)
+    for k in ("x", "y", "z", "status", "iters"):
+        assert np.array_equal(ref[k], mono[k]) and np.array_equal(hinted[k], ref[k]), k
+    for k in ("x", "y", "status", "iters"):
+        assert np.array_equal(host[k], ref[k]), k
+
+
 @pytest.mark.parametrize("name,N,B", [("quadrotor", 50, 40), ("quadrotor", 100, 12), ("cartpole", 100, 30)])
 def test_long_horizons_vs_oracle(built, name, N, B):
     """long horizons run the global-block kernels, the longest ones with z and y in the slab as well (one more workgroup per
