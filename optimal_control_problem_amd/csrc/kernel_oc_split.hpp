@@ -32,7 +32,7 @@ struct OcLds {
 template <int NW, bool SETUP = false>
 __device__ __forceinline__ OcLds<NW> oc_lds(double *lds, const DevPlan &pl, const DevRes &rs, const DevOc &oc) {
   OcLds<NW> L;
-  L.X = lds + rs.stage; L.Q = L.X + pl.npad; L.R = L.Q + pl.npad;
+  L.X = lds + rs.stage; L.Q = L.X + pl.npad; L.R = SETUP ? L.Q : L.Q + pl.npad;      // (SETUP: q lives in the slab, where the iteration kernel picks it up)
   double *rend = L.R + pl.npad + rs.rext;
   // (SETUP: the set-up kernel's own vector layout -- it never touches z, whose region holds its 16-bit index tables and is oc.zpad doubles long, and keeps
   // one n-vector of the Ruiz passes in y)
@@ -161,11 +161,9 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
   if (reuse) {
     prev_status = io.status[b];
     c = io.cscale[b];
-    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = Dg[t]; }
+    for (int t = tid; t < npad; t += NT) { if (pl.perm[t] < 0) Qs[t] = 0.0; cx.R[t] = Dg[t]; }      // (q in place in the slab: padding positions here, the variables' below)
     bsync<NW>();
-    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
-    bsync<NW>();
-    for (int t = tid; t < npad; t += NT) cx.Q[t] *= c * cx.R[t];
+    for (int j = tid; j < n; j += NT) { const int t = pl.pos[j]; Qs[t] = inq[j] * (c * cx.R[t]); }
     double chg[1] = {0.0};
     for (int i = tid; i < mpad; i += NT) {
       const double ei = Eg[i];
@@ -209,10 +207,10 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     // (the ten passes gather through these: a read from LDS instead of a round trip to the L2 in front of every batch)
     if constexpr (sizeof(*iA) == 2) { for (long e = tid; e < pl.A.entries; e += NT) iA[e] = (unsigned short)pl.A.idx[e]; }
     if constexpr (sizeof(*iP) == 2) { for (long e = tid; e < pl.P.entries; e += NT) iP[e] = (unsigned short)pl.P.idx[e]; }
-    for (int t = tid; t < npad; t += NT) { cx.Q[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }
+    for (int t = tid; t < npad; t += NT) { if (pl.perm[t] < 0) Qs[t] = 0.0; cx.R[t] = 1.0; cx.X[t] = 0.0; }      // (q in place in the slab: one workgroup writes it, padding here)
     for (int i = tid; i < mpad; i += NT) cx.W[i] = 1.0;
     bsync<NW>();
-    for (int j = tid; j < n; j += NT) cx.Q[pl.pos[j]] = inq[j];
+    for (int j = tid; j < n; j += NT) Qs[pl.pos[j]] = inq[j];
     bsync<NW>();
     TS(0);
     // ---- modified Ruiz equilibration: D in R, E in W; X = the column-norm accumulators of the sweep over A (one sweep by rows gives the row norm,
@@ -253,7 +251,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       for (int ch = wid; ch < pl.P.nchunks; ch += NW) {
         const int t = ch * WAVE + lane;
         const double x = ell_chunk_mx(sP, iP, cx.R, cx.coP[ch], cx.coP[ch + 1], lane);
-        if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * cx.Q[t])); }
+        if (t < npad) { nPv[t] = x; v[1] += c * cx.R[t] * x; v[0] = fmax(v[0], fabs(c * cx.R[t] * Qs[t])); }
       }
       v[0] = wave_max(v[0]); v[1] = wave_sum(v[1]);
       if (lane == 0) { cx.RED[2 * wid] = v[0]; cx.RED[2 * wid + 1] = v[1]; }
@@ -296,7 +294,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
       }
     }
     bsync<NW>();
-    for (int t = tid; t < npad; t += NT) { cx.Q[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
+    for (int t = tid; t < npad; t += NT) { Qs[t] *= c * cx.R[t]; Dg[t] = cx.R[t]; }
     for (int i = tid; i < mpad; i += NT) {
       const double ei = cx.W[i];
       Eg[i] = ei;
@@ -311,7 +309,6 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
     else if (a_lds) scale_phase(lds, valP, pl.A.idx, pl.P.idx);
     else scale_phase(valA, valP, pl.A.idx, pl.P.idx);
   }
-  for (int t = tid; t < npad; t += NT) Qs[t] = cx.Q[t];         // the scaled q crosses to the iteration kernel through the slab
   bsync<NW>();
   // a kept factor belongs to the rho it was built with: that instance's final rho of the previous solve
   cx.rho = uni(reuse ? io.info[4L * b + 3] : fmin(fmax(io.rho0 && io.rho0[b] > 0.0 ? io.rho0[b] : st.rho, Q_RHO_MIN), Q_RHO_MAX));

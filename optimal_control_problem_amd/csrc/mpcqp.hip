@@ -514,31 +514,40 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   if (h->oc) {      // (after the tables are uploaded: the set-up kernel's copies of the arguments)
     h->doc_setup = h->doc; h->lds_setup = h->lds;
     if (h->split) {
-      // the set-up as four-wave workgroups with their own LDS request -- the factorisation's scratch blocks and assembly records, or the staged values of A
-      // and P where they fit 80 KB beside the vectors, instead of the iteration kernel's block slots -- and their own vector layout: z is never touched and
-      // y holds one n-vector of the Ruiz passes (kernel_oc_split.hpp oc_lds).  Measured (x 8192): cart-pole N=100 set-up kernel 5.61 -> 4.29 ms,
-      // quadrotor N=30 3.49 -> 2.73, N=10 1.81 -> 1.44, N=50 8.50 -> 8.29 (two four-wave workgroups instead of one of eight)
+      // The set-up as four-wave workgroups with their own LDS request -- the factorisation's scratch blocks and assembly records, the staged values of A
+      // and P where they fit, their 16-bit index tables where those fit too -- and their own vector layout: q stays in the slab, z is never touched, y
+      // holds one n-vector of the Ruiz passes (kernel_oc_split.hpp oc_lds).  Three workgroups per CU (the kernel's 164 VGPRs allow no more) beat two
+      // wherever A's values still fit beside them, and so does an unstaged third against a half-staged pair; a fully staged pair beats an unstaged
+      // three.  Measured (x 8192 unless said, set-up kernel, ms): quadrotor N=20 A + P + index tables at two per CU 2.47, A alone at three 2.35, nothing
+      // staged at three 3.26 (round-4 mid build); cart-pole N=50 2.14 / 1.95; cart-pole N=100 A staged at two 4.28, nothing staged at three 3.99;
+      // quadrotor N=50 nothing fits: two per CU 8.05, squeezed to three 8.55 (not taken: the footprint is what the layout needs).  DESIGN.md 3.9
       const Plan &pq = h->plan; DevRes &ds = h->dres_setup; DevOc &dd = h->doc_setup;
       const long scratch = 8L * BLK + ((4L * pq.nblk + 15) / 16) * 16;                 // (plan.hpp oc_stage_doubles: OC_LDL_SCR blocks + the assembly records)
-      dd.ix16 = 0; dd.zpad = 0;
-      const long vec = 3L * pq.npad + oc_rext(h->variant) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4 + 64;
+      const long vec = 2L * pq.npad + oc_rext(h->variant) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4;      // x, r; w; y (an n-vector here); the reduction scratch
       const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
-      const long cap = (getenv("MPCQP_SETUP_CAP") ? atol(getenv("MPCQP_SETUP_CAP")) : 80 * 1024) / 8, cu = 160L * 1024;
-      long stage = scratch; dd.a_lds = dd.p_lds = 0;
-      if (std::max(scratch, (long)pq.A.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries()); dd.a_lds = 1; }
-      if (dd.a_lds && std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()) + vec + tabw <= cap) { stage = std::max(scratch, (long)pq.A.entries() + (long)pq.P.entries()); dd.p_lds = 1; }
-      stage = (stage + 15) / 16 * 16;
-      long vecs = vec;
-      if (dd.a_lds && dd.p_lds && pq.npad < 65536 && !getenv("MPCQP_NO_IX16")) {
-        // with both value arrays staged, the index arrays of A (and P) as 16-bit tables in the z region where that does not cost a workgroup per CU: the ten
-        // Ruiz passes then gather without a round trip to the L2 in front of every batch
-        const long zA = ((long)pq.A.entries() / 4 + 15) / 16 * 16, zAP = (((long)pq.A.entries() + (long)pq.P.entries()) / 4 + 15) / 16 * 16;
-        const long base = (stage + vecs + tabw) * 8;
-        if (base + zAP * 8 <= cap * 8 && cu / (base + zAP * 8) == cu / base) { dd.ix16 = 3; dd.zpad = (int)zAP; }
-        else if (base + zA * 8 <= cap * 8 && cu / (base + zA * 8) == cu / base) { dd.ix16 = 1; dd.zpad = (int)zA; }
-        vecs += dd.zpad;
-      }
-      ds.stage = stage; h->setup_nw = 4; h->lds_setup = (stage + vecs + tabw) * 8;
+      const long cu = 160L * 1024, nA = (long)pq.A.entries(), nP = (long)pq.P.entries();
+      struct Shape { long stage, bytes; int a, p, ix16, zpad; bool fits; };
+      auto shape = [&](const long cap_bytes) {
+        const long cap = cap_bytes / 8;
+        Shape r{scratch, 0, 0, 0, 0, 0, false};
+        if (std::max(scratch, nA) + vec + tabw <= cap) { r.stage = std::max(scratch, nA); r.a = 1; }
+        if (r.a && std::max(scratch, nA + nP) + vec + tabw <= cap) { r.stage = std::max(scratch, nA + nP); r.p = 1; }
+        r.stage = (r.stage + 15) / 16 * 16;
+        long total = r.stage + vec + tabw;
+        if (r.a && r.p && pq.npad < 65536 && !getenv("MPCQP_NO_IX16")) {      // (the ten Ruiz passes then gather without a round trip to the L2 in front of every batch)
+          const long zA = (nA / 4 + 15) / 16 * 16, zAP = ((nA + nP) / 4 + 15) / 16 * 16;
+          if (total + zAP <= cap) { r.ix16 = 3; r.zpad = (int)zAP; } else if (total + zA <= cap) { r.ix16 = 1; r.zpad = (int)zA; }
+          total += r.zpad;
+        }
+        r.bytes = total * 8; r.fits = total <= cap;
+        return r;
+      };
+      Shape sh = shape(cu / 2);
+      if (const char *e = getenv("MPCQP_SETUP_CAP")) sh = shape(atol(e));
+      else { const Shape s3 = shape(cu / 3); if (s3.fits && (s3.a || !(sh.a && sh.p))) sh = s3; }
+      dd.a_lds = sh.a; dd.p_lds = sh.p; dd.ix16 = sh.ix16; dd.zpad = sh.zpad;
+      ds.stage = sh.stage; h->setup_nw = 4; h->lds_setup = sh.bytes;
+      const long vecs = vec + sh.zpad;
       if (h->oc8) {
         int nb = 0; h->qslots = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, oc_admm_of(h, false), h->variant * WAVE, (size_t)h->lds) == hipSuccess && nb > 0) {
