@@ -653,8 +653,28 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
   }
   const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
   int *ticket = reinterpret_cast<int *>(L.RED + 16 * NW);      // (the spare words in front of the chain tables)
+  if (threadIdx.x == 0) { ticket[1] = 0; ticket[2] = 0; ticket[3] = 0; }
   for (;;) {
-    if (threadIdx.x == 0) *ticket = atomicAdd(io.queue, 1);
+    if (!oc.resume) { if (threadIdx.x == 0) *ticket = atomicAdd(io.queue, 1); }
+    else if (threadIdx.x < WAVE) {
+      // a resume launch serves the few instances that left the launch before: tickets are drawn 64 at a time, the wave looks at their status words together
+      // and keeps the waiting ones as a bit mask (one ticket and one barrier pair per instance made an all-idle launch of 8192 cost 0.1 - 0.2 ms)
+      int base = ticket[1]; unsigned long long mask = ((unsigned long long)(unsigned)ticket[3] << 32) | (unsigned)ticket[2];
+      while (mask == 0ull && base < io.count) {
+        int b0 = 0;
+        if (threadIdx.x == 0) b0 = atomicAdd(io.queue, WAVE);
+        base = __builtin_amdgcn_readfirstlane(b0);
+        const int t = base + (int)threadIdx.x;
+        int st_ = 0;
+        if (t < io.count) st_ = io.status[io.order ? io.order[t] : t];
+        mask = __ballot(st_ == OC_PENDING || st_ == OC_PENDING_NONCVX);
+      }
+      if (threadIdx.x == 0) {
+        if (mask == 0ull) *ticket = io.count;
+        else { *ticket = base + __builtin_ctzll(mask); mask &= mask - 1; }
+        ticket[1] = base; ticket[2] = (int)(unsigned)(mask & 0xffffffffull); ticket[3] = (int)(unsigned)(mask >> 32);
+      }
+    }
     bsync<NW>();
     const int t = __builtin_amdgcn_readfirstlane(*ticket);
     if (t >= io.count) break;
