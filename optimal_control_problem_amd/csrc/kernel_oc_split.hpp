@@ -409,6 +409,7 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
     if (w == 2) oc_touch_pinned(valA, pl.A.entries * 8, lane);
     else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
   };
+  [[maybe_unused]] const OcChain occ = oc_chain_info<NW>(oc, octab, wid, lane);      // (after the tables are in LDS)
   const int myAt = oc_my_chunks<NW>(TL ? oc.tl.Atr_off : pl.At.chunk_off, pl.At.nchunks, wid, lane), myA = oc_my_chunks<NW>(TL ? oc.tl.Ar_off : pl.A.chunk_off, pl.A.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
   // TL: this wave's tile records, read once into the lanes of registers (picked out with v_readlane inside the sweeps: no table access in front of a chunk's loads).
   //   A' sweep, lane 4 k + u: the tile of column block u of the wave's k-th chunk (or the zero tile) and the first of its sixteen rows of w
@@ -507,7 +508,7 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
 #endif
 #ifndef MPCQP_VALU_CHAINS     // (experiment, -DMPCQP_VALU_CHAINS: the chains on the vector ALUs too -- oc_solve_v: parity-green, 4 - 20 % slower)
       if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
-      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
+      else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, occ, stamps);
 #else
       oc_solve_v<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, idle_touch, stamps);
 #endif

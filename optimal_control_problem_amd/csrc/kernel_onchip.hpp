@@ -31,6 +31,7 @@ struct DevTile {
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
+  int npair, o_pair;   // twisted pairs of chains (plan.hpp OcPlan::pairs) and their records in tab: {LE, LF, oE, oF, junc, sLE, sLF, soE, soF, -, -, -}
   int nfill, o_s, o_dbl, ndbl, o_pp;   // LDS slots filled from the slab; the chains the solve walks; its double stages and their product blocks (plan.hpp oc_add_doubles)
   int at_poll, at_free;   // chunks of A' whose rows the iteration computes during the chain phase instead of before it (-1: none); see oc_solve
   int a_lds, p_lds; // the ELL values of A (and of P behind them) fit the LDS block slots: they stay there while the problem is scaled
@@ -414,13 +415,19 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
                                        unsigned long long *t_sweep = nullptr) {
   static_assert(NW >= 4, "two chain waves and their two helpers (further waves only take part in the barriers)");
   // scratch blocks: 0..3 G hand-over [chain][step parity], 4 chain E's term for the junction's diagonal block, 5 for its hub block, 6..7 the helpers' sums
-  const int LE = oc_tab(ctab, 0), LF = oc_tab(ctab, 1);
-  const bool junc = oc.junc && LF > 0;
-  const int S = junc ? max(LE + 1, LF) : LE;          // chain steps run in phases 0 .. S - 1 (chain F keeps its last step, the junction, for phase S - 1); helpers one phase behind
   const int ch = wid & 1;
   const bool helper = NW > 4 ? (wid == 2 || wid == 3) : wid >= 2, idle = NW > 4 && wid >= 4;
-  const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
   const int *pt = oc.tab + oc.o_pos;
+  bool ok = true;
+  d4 Sh = {0, 0, 0, 0};
+  // (several twisted pairs -- the dissected order -- are taken one after the other by the same four waves: their chains are short, and the pairs only meet in
+  // the hub's diagonal block, whose sums the helpers carry across)
+  for (int pi = 0; pi < oc.npair; pi++) {
+  const int rec = oc.o_pair + 12 * pi;
+  const int LE = oc_tab(ctab, rec), LF = oc_tab(ctab, rec + 1);
+  const bool junc = oc_tab(ctab, rec + 4) && LF > 0;
+  const int S = junc ? max(LE + 1, LF) : LE;          // chain steps run in phases 0 .. S - 1 (chain F keeps its last step, the junction, for phase S - 1); helpers one phase behind
+  const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc_tab(ctab, rec + 2) : oc_tab(ctab, rec + 3);
   // block ids of the chain's steps, step i in lane i (read back with v_readlane: no memory latency inside a phase)
   const int pv = L > 0 ? ctab[cb + 2 * min(lane, L - 1)] : 0;
   const int gsv = pt[5 * pv], csv = pt[5 * pv + 1], hsv = pt[5 * pv + 2];
@@ -431,8 +438,7 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
     if (s < LF - 1) return s;
     return (s == S - 1 && LF > 0) ? LF - 1 : -1;
   };
-  bool ok = true;
-  d4 Dc = {0, 0, 0, 0}, Wp = {0, 0, 0, 0}, Hr = {0, 0, 0, 0}, Lc = {0, 0, 0, 0}, Ln = {0, 0, 0, 0}, Sn = {0, 0, 0, 0}, Hc = {0, 0, 0, 0}, Hn = {0, 0, 0, 0}, Sh = {0, 0, 0, 0};
+  d4 Dc = {0, 0, 0, 0}, Wp = {0, 0, 0, 0}, Hr = {0, 0, 0, 0}, Lc = {0, 0, 0, 0}, Ln = {0, 0, 0, 0}, Sn = {0, 0, 0, 0}, Hc = {0, 0, 0, 0}, Hn = {0, 0, 0, 0};
   int pend = -1;
   // Slab operands are fetched a whole step ahead (a slab read is an L2 / fabric round trip of a few thousand cycles).  What a fetch may
   // read early: L_k and the diagonal block below it are first written by this chain wave at step k (W over L: one phase after, see
@@ -501,6 +507,7 @@ __device__ __forceinline__ bool oc_ldl(const DevOc &oc, const int *ctab, double 
     bsync<NW>();
   }
   if (!helper && !idle && pend >= 0) oc_stA(slab + (long)pend * BLK, lane, Wp);
+  }
   if (HUB) {
     if (helper) oc_stS(scr + (6 + ch) * BLK, lane, Sh);
     bsync<NW>();
@@ -772,10 +779,32 @@ __device__ __forceinline__ void oc_solve(const DevOc &oc, const int *tab, const 
   if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
 #undef OC_TS
 }
+// what a wave needs to know about the chain it walks in the solve (oc_solve_long): read once per kernel, not once per ADMM iteration -- the pair's record,
+// the chain's table and the junction are three dependent table reads, and with several pairs the junctions of all of them are wanted by their owners
+struct OcChain {
+  int chainw, role, pjunc, len, cb, f, xs;   // chain wave?  E (0) or F (1); the pair has a junction; positions; table offset; the junction (or -1); the junction term's vector block
+  int fv;                                    // lane i: the junction of pair i (or -1)
+};
+template <int NW>
+__device__ __forceinline__ OcChain oc_chain_info(const DevOc &oc, const int *tab, const int wid, const int lane) {
+  OcChain c;
+  const int np = oc.npair, pair = wid >> 1;
+  c.chainw = wid < 2 * np; c.role = wid & 1;
+  const int rec = oc.o_pair + 12 * (c.chainw ? pair : 0);
+  const int LE = oc_tab(tab, rec + 5), LF = oc_tab(tab, rec + 6);
+  c.pjunc = oc_tab(tab, rec + 4);
+  c.len = c.role == 0 ? LE : LF; c.cb = c.role == 0 ? oc_tab(tab, rec + 7) : oc_tab(tab, rec + 8);
+  c.xs = pair == 0 ? 0 : NW + 1 + pair;
+  int fv = -1;
+  if (lane < np) { const int ri = oc.o_pair + 12 * lane, lf = tab[ri + 6]; if (tab[ri + 4] && lf > 0) fv = tab[tab[ri + 8] + 2 * (lf - 1)]; }
+  c.fv = fv;
+  c.f = c.chainw ? __builtin_amdgcn_readlane(fv, c.chainw ? pair : 0) : -1;
+  return c;
+}
 template <int NW, int NG, int NH, bool HUB, class Late, class Idle>
 __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, const double *BL, double *R, const int npad, const OcLane &ln_, const OcWave<NG> &ow_,
                                          const d4 (&G)[NG], const d4 (&HF)[NH > 0 ? NH : 1], const d4 (&HT)[NH > 0 ? NH : 1], const int wid,
-                                         volatile int *ticket, const int iter, Late &&late, Idle &&idle, unsigned long long *stamp = nullptr) {
+                                         volatile int *ticket, const int iter, Late &&late, Idle &&idle, const OcChain &ci, unsigned long long *stamp = nullptr) {
   // The LDS addresses of a wave's positions and block slots do not change from one ADMM iteration to the next, so the compiler computes them
   // once, outside the iteration -- and in the eight-wave instances, whose registers mostly hold resident blocks, spills them: every use then
   // is a scratch reload with a full wait in front of an LDS read (38 per solve, ~19k cycles per iteration measured).  Their inputs are made
@@ -792,16 +821,17 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
 #endif
   double *EXT = R + npad;                          // vector blocks behind the solve vector
   // (the chains the SOLVE walks: with double stages they visit every other position; plan.hpp oc_add_doubles)
-  const int LE = oc_tab(tab, oc.o_s), LF = oc_tab(tab, oc.o_s + 1);
-  const int len = wid == 0 ? LE : LF, cb = wid == 0 ? oc.o_s + 2 : oc.o_s + 2 + 2 * LE;
-  const int f = (oc.junc && LF > 0) ? oc_tab(tab, oc.o_s + 2 + 2 * LE + 2 * (LF - 1)) : -1;
+  // chain waves 2 i (E) and 2 i + 1 (F) walk twisted pair i (one pair: the plain or twisted order; several: the dissected order, plan.hpp); the junction term
+  // of pair i waits in vector block xs = 0 (pair 0) or NW + 1 + i behind the solve vector
+  const int np = oc.npair, role = ci.role, pjunc = ci.pjunc, len = ci.len, cb = ci.cb, f = ci.f, xs = ci.xs;
+  const bool chainw = ci.chainw;
   const int H = oc.nbc;
   if (oc.ndbl) { oc_double_phase<NW, 0>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   // ---- F1
   // Two stages per trip with the roles of the two vector register sets swapped (x -> y -> x): no copy sits between an MFMA result
   // and the MFMAs that read it as their B operand.  The next stage's block and right-hand side are loaded while a stage multiplies;
   // table entries are read two stages ahead.
-  if (wid < 2 && len > 0) {
+  if (chainw && len > 0) {
     const int nst = len - 1;                           // stages: stage k multiplies block e[k].y into position e[k + 1].x
     // (table reads past the end are clamped to the last entry: the trip body has no branch, which keeps the compiler's wait counts exact)
     int2 e0 = oc_pair(tab, cb), e1 = oc_pair(tab, cb + 2 * min(1, nst)), e2 = oc_pair(tab, cb + 2 * min(2, nst)), e3 = oc_pair(tab, cb + 2 * min(3, nst));
@@ -837,12 +867,15 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
       x = oc_bc4(r0); e0 = e1;
     }
     // x = t of the chain's last position e0.x
-    if (wid == 0 && oc.junc) oc_stB4(EXT, 0, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
-  } else if (wid >= 2) late(wid);
+    if (role == 0 && pjunc) oc_stB4(EXT, xs, ln, oc_mv4x4(oc_ldF4(BL + (long)e0.y * BLK, ln), x, 0.0));
+  } else if (!chainw) late(wid);
   bsync<NW>();
   if (oc.ndbl) { oc_double_phase<NW, 1>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
   OC_TS(0);
-  if (f >= 0 && wid == (f & (NW - 1))) oc_stB4(R, f, ln, oc_ldE4(R, f, ln) + oc_ldE4(EXT, 0, ln));      // t_f complete (its owner reads it back in order)
+  for (int i = 0; i < np; i++) {      // t_f complete, pair by pair (its owner in the wave-parallel phases reads it back in order)
+    const int fi = __builtin_amdgcn_readlane(ci.fv, i);
+    if (fi >= 0 && wid == (fi & (NW - 1))) oc_stB4(R, fi, ln, oc_ldE4(R, fi, ln) + oc_ldE4(EXT, i == 0 ? 0 : NW + 1 + i, ln));
+  }
   const double xhd = oc_hub_phases<NW, NG, NH, HUB>(oc, BL, R, EXT, threadIdx.x & 63, ow, G, HF, HT, wid);
   OC_TS(1);
   bsync<NW>();
@@ -850,11 +883,11 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
   OC_TS(2);
   // ---- B2
   if (HUB && wid == NW - 1) oc_stV(R, H, threadIdx.x & 63, xhd);     // only now: every wave has read the hub's right-hand side
-  if (wid < 2 && len > 0) {
+  if (chainw && len > 0) {
     // stages run down the chain table: stage k computes x_e[k].x = d_e[k].x + block(e[k].y)' v, v = x of the position above it
     int k = len - 2;
     d4 x;
-    if (wid == 0 && oc.junc) { x = oc_ldB4(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
+    if (role == 0 && pjunc) { x = oc_ldB4(R, f, ln); k = len - 1; }       // chain E starts below f, which chain F's owner finished in B1
     else x = oc_ldB4(R, tab[cb + 2 * (len - 1)], ln);
     if (k >= 0) {
       int2 e0 = oc_pair(tab, cb + 2 * k), e1 = oc_pair(tab, cb + 2 * max(k - 1, 0)), e2 = oc_pair(tab, cb + 2 * max(k - 2, 0)), e3 = oc_pair(tab, cb + 2 * max(k - 3, 0));
@@ -880,7 +913,7 @@ __device__ __forceinline__ void oc_solve_long(const DevOc &oc, const int *tab, c
       while (k >= 1) trip2();
       if (k == 0) oc_stB4(R, e0.x, ln, oc_mv4x4(a, x, c));
     }
-  } else if (wid >= 2) idle(wid);       // (waves 2, 3 have nothing to do in this phase: the caller's prefetch of what the next phase streams)
+  } else if (!chainw) idle(wid);       // (waves without a chain have nothing to do in this phase: the caller's prefetch of what the next phase streams)
   bsync<NW>();
   if (oc.ndbl) { oc_double_phase<NW, 3>(oc, tab, BL, R, ln, wid); bsync<NW>(); }
 #undef OC_TS

@@ -339,7 +339,21 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     if ((h->oc8 < 0 || (want > 0 && h->gblocks && !h->oc && !variant_request() && !getenv("MPCQP_NO_OC8") && !getenv("MPCQP_NO_OC"))) && small_ok) {
       Plan p8 = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 3 : -1, 2);
       h->oc8 = 0;
-      if (p8.error.empty()) {
+      if (twist && !getenv("MPCQP_NO_DISSECT")) {
+        // the dissected order first (plan.hpp build_plan ordering 4): separators of the stage chain in the hub block where it has room, several twisted pairs of
+        // short chains instead of one pair of long ones
+        Plan pd = build_plan(n, m, Pp, Pi, Ap, Ai, 4, 2);
+        if (pd.error.empty()) {
+          const ResPlan rd = build_res_plan(pd, 8, false);
+          for (int k = 0; k < 2 && !h->oc8; k++) {
+            const OcPlan o = build_oc_plan(pd, 8, 1 << 20, OC8_INST[k].ng, OC8_INST[k].nh, OC8_MAX_CHAIN);
+            if (o.ok && o.has_hub && o.pairs.size() > 1 && lds_bytes_oc(pd, rd, o, OC8_INST[k].zyg) <= OC8_LDS_MAX) {
+              h->ocplan = o; h->oc8 = k + 1; h->oc = true; h->gblocks = true; h->zyg = OC8_INST[k].zyg; want = 8; p4 = pd;
+            }
+          }
+        }
+      }
+      if (!h->oc8 && p8.error.empty()) {
         const ResPlan r8 = build_res_plan(p8, 8, false);
         for (int k = 0; k < 2 && !h->oc8; k++) {
           const OcPlan o = build_oc_plan(p8, 8, 1 << 20, OC8_INST[k].ng, OC8_INST[k].nh, OC8_MAX_CHAIN);
@@ -455,10 +469,10 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
     memset(&h->doc, 0, sizeof(h->doc));
     if (h->oc) {
       const OcPlan &o = h->ocplan; DevOc &d = h->doc;
-      dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = oc_rext(rp.nw); dr.nconst = 0; dr.n_seg = 0;
+      dr.stage = oc_stage_doubles(o, rp, pl); dr.rext = oc_rext(rp.nw, std::max<int>(1, (int)o.pairs.size())); dr.nconst = 0; dr.n_seg = 0;
       d.nbc = o.nbc; d.has_hub = o.has_hub; d.junc = o.junc; d.npw = o.npw; d.nhr = o.nhr; d.nlds = o.nlds; d.ntab = (int)o.tab.size();
       d.o_chainE = o.o_chainE; d.o_chainF = o.o_chainF; d.o_pos = o.o_pos; d.o_fill = o.o_fill; d.ghub_slot = o.ghub_slot; d.ghub_src = o.ghub_src;
-      d.nfill = o.nfill; d.o_s = o.o_s; d.o_dbl = o.o_dbl; d.ndbl = (int)o.dbl.size(); d.o_pp = o.o_pp;
+      d.npair = (int)o.pairs.size(); d.o_pair = o.o_pair; d.nfill = o.nfill; d.o_s = o.o_s; d.o_dbl = o.o_dbl; d.ndbl = (int)o.dbl.size(); d.o_pp = o.o_pp;
       d.at_poll = d.at_free = -1;
       // (opt-in since the chains run on the 4-block MFMA: they now reach the ticket before wave 3 has the rows -- 913k with, 917k without)
       // (single-kernel four-wave instance only: the eight-wave solve, oc_solve_long, has no ticket wait, and the two-kernel form sweeps all of A' up front)
@@ -523,7 +537,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // quadrotor N=50 nothing fits: two per CU 8.05, squeezed to three 8.55 (not taken: the footprint is what the layout needs).  DESIGN.md 3.9
       const Plan &pq = h->plan; DevRes &ds = h->dres_setup; DevOc &dd = h->doc_setup;
       const long scratch = 8L * BLK + ((4L * pq.nblk + 15) / 16) * 16;                 // (plan.hpp oc_stage_doubles: OC_LDL_SCR blocks + the assembly records)
-      const long vec = 2L * pq.npad + oc_rext(h->variant) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4;      // x, r; w; y (an n-vector here); the reduction scratch
+      const long vec = 2L * pq.npad + oc_rext(h->variant, std::max<int>(1, (int)h->ocplan.pairs.size())) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4;      // x, r; w; y (an n-vector here); the reduction scratch
       const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
       const long cu = 160L * 1024, nA = (long)pq.A.entries(), nP = (long)pq.P.entries();
       struct Shape { long stage, bytes; int a, p, ix16, zpad; bool fits; };

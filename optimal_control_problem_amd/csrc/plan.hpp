@@ -242,7 +242,7 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
   // [0, k-1, 1, k-2, ...]: the elimination tree becomes two chains that meet in the middle -- same block count, half
   // the sequential depth (two waves eliminate / substitute concurrently).
   bool twisted = false;
-  if (force_ordering >= 2) {
+  if (force_ordering >= 2 && force_ordering != 4) {
     int nonhub = 0;   // hubs sit behind all non-hubs; count the leading variables that kept relative order 0..r-1
     {
       std::vector<int> inv(n, -1);
@@ -280,7 +280,68 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
       }
     }
   }
-  pl.ordering = use_hub ? (twisted ? 2 : 1) : 0;
+  // ordering 4 ("dissected"): where the hub block has room beside the hub variables, vertex separators of the chain move into it -- the variables right of a cut
+  // that a variable left of it couples to (the state x_s of one stage of an OCP) -- and the chain falls apart into segments that only the hub connects.  Every
+  // segment is whole blocks, twisted by itself: twice as many elimination chains per separator, each a fraction of the length, and no block more (the fill
+  // of a separator lands in the hub blocks W_hub,p, which every column has anyway).  Cart-pole N=100: 3 separators of 4 states beside the 4 parameters,
+  // four segments of 8 blocks, eight chains of 4 where the twisted order has two of 16.
+  bool dissected = false;
+  if (force_ordering == 4 && use_hub) {
+    int nonhub = n;
+    std::vector<int> inv(n, -1);
+    for (int v = 0; v < n; v++) inv[pos_hub[v]] = v;
+    for (int t = 1; t < n; t++) if (inv[t] < inv[t - 1]) { nonhub = t; break; }
+    const int nhubv = n - nonhub;
+    // right boundary of every cut: rb[c] = non-hub variables at order >= c with a neighbour at order < c
+    auto right_boundary = [&](int c) {
+      std::vector<int> r;
+      for (int t = c; t < nonhub && t < c + 4 * BS; t++) { const int w = inv[t]; for (int v : adj[w]) if (pos_hub[v] < c) { r.push_back(t); break; } }
+      return r;
+    };
+    int s0 = BS + 1;
+    for (int c = BS; c + BS <= nonhub; c++) s0 = std::min(s0, (int)right_boundary(c).size());
+    const int want_sep = 3;
+    const int S = (nhubv > 0 && nhubv < BS && s0 >= 1 && s0 <= BS) ? std::min(want_sep, (BS - nhubv) / s0) : 0;
+    if (S >= 1 && nonhub >= 4 * BS * (S + 1)) {
+      std::vector<char> is_sep(nonhub, 0);
+      std::vector<int> cuts;
+      bool okc = true;
+      for (int i = 1; i <= S && okc; i++) {
+        const int ideal = (int)((long)i * nonhub / (S + 1));
+        int best = -1;
+        for (int d = 0; d <= 2 * BS && best < 0; d++) for (int c : {ideal - d, ideal + d}) {
+          if (c <= (cuts.empty() ? BS : cuts.back() + 2 * BS) || c + BS > nonhub) continue;
+          if ((int)right_boundary(c).size() == s0) { best = c; break; }
+        }
+        if (best < 0) { okc = false; break; }
+        for (int t : right_boundary(best)) is_sep[t] = 1;
+        cuts.push_back(best);
+      }
+      if (okc) {
+        std::vector<int> pos_ds(n, -1);
+        int base = 0, ci = 0, cnt = 0, seg_first = 0;
+        std::vector<std::pair<int, int>> segs;      // [first order index, one past the last) of every segment
+        for (int i = 0; i <= S; i++) { const int a = i == 0 ? 0 : cuts[i - 1], b = i == S ? nonhub : cuts[i]; segs.push_back({a, b}); }
+        (void)ci; (void)cnt; (void)seg_first;
+        for (auto &sg : segs) {
+          std::vector<int> mem;
+          for (int t = sg.first; t < sg.second; t++) if (!is_sep[t]) mem.push_back(inv[t]);
+          const int kb = ((int)mem.size() + BS - 1) / BS;
+          for (size_t r = 0; r < mem.size(); r++) {
+            const int b = (int)r / BS, nbk = b < (kb + 1) / 2 ? 2 * b : 2 * (kb - 1 - b) + 1;
+            pos_ds[mem[r]] = base + nbk * BS + (int)r % BS;
+          }
+          base += kb * BS;
+        }
+        int h = base;
+        for (int t = nonhub; t < n; t++) pos_ds[inv[t]] = h++;
+        for (int t = 0; t < nonhub; t++) if (is_sep[t]) pos_ds[inv[t]] = h++;
+        if (h <= base + BS) { pos_hub = pos_ds; npad_hub = base + BS; twisted = true; dissected = true; }
+      }
+    }
+    if (!dissected) { pl.error = "the dissected ordering does not apply"; return pl; }
+  }
+  pl.ordering = use_hub ? (dissected ? 4 : twisted ? 2 : 1) : 0;
   pl.pos = use_hub ? pos_hub : pos_nat;
   pl.npad = use_hub ? npad_hub : npad_nat;
   pl.nb = pl.npad / BS;
@@ -794,6 +855,11 @@ struct OcPlan {
   bool ok = false;
   int nbc = 0, has_hub = 0, junc = 0;
   std::vector<int> chainE, chainF;          // positions in elimination (forward) order
+  // Several twisted pairs (the dissected ordering, build_plan ordering 4): pairs[0] = {chainE, chainF, junc}; the chains of one pair meet in their junction,
+  // pairs meet nowhere but in the hub.  Chain waves 2 i, 2 i + 1 walk pair i in the solve; the factorisation takes the pairs one after the other.
+  struct Pair { std::vector<int> E, F; int junc = 0; int oE = 0, oF = 0; };
+  std::vector<Pair> pairs;
+  int o_pair = 0;                            // in tab: per pair {LE, LF, oE, oF, junc, sLE, sLF, soE, soF, 0, 0, 0} (the s-entries: what the solve walks)
   int npw = 0;                              // positions per wave in the wave-parallel phases: wave w owns p = w + 4 s, s < npw
   int nhr = 0;                              // hub blocks of the positions with s < nhr live in registers (both layouts), the rest in LDS; = the instance's OCH
   int nlds = 0;                             // LDS block slots
@@ -814,7 +880,7 @@ struct OcPlan {
   int nfill = 0;                                          // LDS slots filled from the slab (the product slots behind them are computed on chip)
   int o_s = 0, o_dbl = 0, o_pp = 0;
 };
-inline int oc_rext(int nw) { return (nw + 2) * BS; }     // behind the solve vector: the junction term, one hub partial sum per wave, a zero block
+inline int oc_rext(int nw, int npair = 1) { return (nw + 1 + npair) * BS; }     // behind the solve vector: the junction term, one hub partial sum per wave, a zero block, the junction terms of further pairs
 constexpr int OC_CHAIN_SHORT = 17;          // the four-wave instances unroll their chain loops for 16 stages (kernel_onchip.hpp OC_MAXT); the eight-wave ones loop
 
 // the flat table the kernels read: [0] LE [1] LF, the chains as {position, LDS slot of W_succ(p),p} pairs (8-byte aligned; what oc_ldl walks), at o_s
@@ -840,6 +906,22 @@ inline void oc_build_tab(OcPlan &oc) {
   for (size_t k = 0; k < oc.schainF.size(); k++) { oc.tab.push_back(oc.schainF[k]); oc.tab.push_back(oc.sslotF[k]); }
   oc.o_dbl = (int)oc.tab.size();
   for (const OcPlan::Dbl &d : oc.dbl) { int r[8] = {d.a, d.m, d.b, d.slot_a, d.slot_m, 0, 0, 0}; oc.tab.insert(oc.tab.end(), r, r + 8); }
+  if (oc.pairs.empty()) { OcPlan::Pair p0; p0.E = oc.chainE; p0.F = oc.chainF; p0.junc = oc.junc; oc.pairs.push_back(p0); }
+  {
+    // the lists of the further pairs (one list serves factorisation and solve: no double stages there), then the records
+    for (size_t i = 1; i < oc.pairs.size(); i++) {
+      OcPlan::Pair &pr = oc.pairs[i];
+      pr.oE = (int)oc.tab.size(); for (int p : pr.E) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
+      pr.oF = (int)oc.tab.size(); for (int p : pr.F) { oc.tab.push_back(p); oc.tab.push_back(std::max(oc.cslot[p], 0)); }
+    }
+    oc.o_pair = (int)oc.tab.size();
+    for (size_t i = 0; i < oc.pairs.size(); i++) {
+      const OcPlan::Pair &pr = oc.pairs[i];
+      int r[12] = {(int)pr.E.size(), (int)pr.F.size(), pr.oE, pr.oF, pr.junc, (int)pr.E.size(), (int)pr.F.size(), pr.oE, pr.oF, 0, 0, 0};
+      if (i == 0) { r[2] = oc.o_chainE; r[3] = oc.o_chainF; r[5] = (int)oc.schainE.size(); r[6] = (int)oc.schainF.size(); r[7] = oc.o_s + 2; r[8] = oc.o_s + 2 + 2 * (int)oc.schainE.size(); }
+      oc.tab.insert(oc.tab.end(), r, r + 12);
+    }
+  }
   oc.o_pos = (int)oc.tab.size();
   for (int p = 0; p < nbc; p++) { int r[5] = {oc.gsrc[p], oc.csrc[p], oc.hsrc[p], oc.cslot[p], oc.hslot[p]}; oc.tab.insert(oc.tab.end(), r, r + 5); }
   oc.o_fill = (int)oc.tab.size();
@@ -902,23 +984,34 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
     for (int I : pl.colrows[p]) { if (oc.has_hub && I == H) continue; succ[p] = I; npred[I]++; }
   std::vector<int> heads;
   for (int p = 0; p < nbc; p++) { if (npred[p] == 0) heads.push_back(p); if (npred[p] > 2) return oc; }
-  if (heads.empty() || heads.size() > 2) return oc;
+  if (heads.empty() || (int)heads.size() > nw) return oc;
   auto walk = [&](int h) { std::vector<int> c; for (int p = h; p >= 0; p = succ[p]) c.push_back(p); return c; };
-  std::vector<int> c0 = walk(heads[0]), c1 = heads.size() == 2 ? walk(heads[1]) : std::vector<int>();
-  if (heads.size() == 2) {
-    // the two chains must share exactly their last element
-    if (c0.back() != c1.back()) return oc;
-    for (size_t i = 0; i + 1 < c0.size(); i++) if (std::find(c1.begin(), c1.end(), c0[i]) != c1.end()) return oc;
-    // E = the chain that hands its end over (drops the shared element), F keeps it; give F the longer one so both waves do the same work
-    if (c0.size() > c1.size()) std::swap(c0, c1);
-    c0.pop_back();
-    oc.chainE = c0; oc.chainF = c1; oc.junc = 1;
-    if (oc.chainE.empty()) { oc.junc = 0; oc.chainE = c1; oc.chainF.clear(); }
-  } else {
-    oc.chainE = c0;
+  // chains that end in the same element form a twisted pair; a chain alone is a pair without junction.  One pair: the plain or twisted order; several:
+  // the dissected order, whose segments meet only in the hub (without a hub they would not be one matrix)
+  std::map<int, std::vector<std::vector<int>>> by_end;
+  for (int h : heads) { std::vector<int> c = walk(h); by_end[c.back()].push_back(c); }
+  if (by_end.size() > 1 && (!oc.has_hub || 2 * (int)by_end.size() > nw || nw != 8)) return oc;
+  int total = 0;
+  for (auto &kv : by_end) {
+    std::vector<std::vector<int>> &cs = kv.second;
+    if (cs.size() > 2) return oc;
+    OcPlan::Pair pr;
+    if (cs.size() == 2) {
+      std::vector<int> c0 = cs[0], c1 = cs[1];
+      for (size_t i = 0; i + 1 < c0.size(); i++) if (std::find(c1.begin(), c1.end(), c0[i]) != c1.end()) return oc;      // (they share exactly their last element)
+      // E = the chain that hands its end over (drops the shared element), F keeps it; give F the longer one so both waves do the same work
+      if (c0.size() > c1.size()) std::swap(c0, c1);
+      c0.pop_back();
+      pr.E = c0; pr.F = c1; pr.junc = 1;
+      if (pr.E.empty()) { pr.junc = 0; pr.E = c1; pr.F.clear(); }
+    } else pr.E = cs[0];
+    if ((int)pr.E.size() > max_chain || (int)pr.F.size() > max_chain) return oc;        // (the four-wave kernels' chain loops are unrolled for 16 stages)
+    total += (int)(pr.E.size() + pr.F.size());
+    oc.pairs.push_back(pr);
   }
-  if ((int)(oc.chainE.size() + oc.chainF.size()) != nbc) return oc;
-  if ((int)oc.chainE.size() > max_chain || (int)oc.chainF.size() > max_chain) return oc;        // (the four-wave kernels' chain loops are unrolled for 16 stages)
+  std::sort(oc.pairs.begin(), oc.pairs.end(), [](const OcPlan::Pair &a, const OcPlan::Pair &b) { return a.E[0] < b.E[0]; });
+  oc.chainE = oc.pairs[0].E; oc.chainF = oc.pairs[0].F; oc.junc = oc.pairs[0].junc;
+  if (total != nbc) return oc;
   oc.npw = (nbc + nw - 1) / nw;
   if (oc.npw > max_npw) return oc;
   oc.gsrc.assign(nbc, -1); oc.csrc.assign(nbc, -1); oc.hsrc.assign(nbc, -1); oc.cslot.assign(nbc, -1); oc.hslot.assign(nbc, -1);
@@ -985,7 +1078,7 @@ inline long lds_bytes_oc(const Plan &pl, const ResPlan &rp, const OcPlan &oc, bo
   // the chain tables live in LDS (the per-position and fill tables are read from global memory), and so do the chunk offsets of A, A', P
   long tab_words = ((long)oc.o_pos + 1) / 2 + 4 + ((long)pl.A.nchunks + pl.At.nchunks + pl.P.nchunks + 3 + 1 + 1) / 2;     // (+ the ticket of the late right-hand side rows)
   if (tp && tp->on) tab_words += ((long)tp->Ar.nchunks + tp->Atr.nchunks + 2 + 1) / 2;      // chunk offsets of the two remainder layouts
-  return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + oc_rext(rp.nw) + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
+  return (oc_stage_doubles(oc, rp, pl) + 3L * pl.npad + oc_rext(rp.nw, std::max<int>(1, (int)oc.pairs.size())) + (zy_global ? 1L : 3L) * pl.mpad + 16L * rp.nw + 16 + 16L * rp.nw + tab_words) * 8L;
 }
 
 inline long lds_bytes(const Plan &pl) {

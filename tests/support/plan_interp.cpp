@@ -424,9 +424,6 @@ bool sweep_d(Wave &a) {
 }
 int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
   const int *tab = oc.tab.data();
-  const int LE = tab[0], LF = tab[1];
-  const bool junc = oc.junc && LF > 0;
-  const int Sph = junc ? std::max(LE + 1, LF) : LE;
   const int *pt = tab + oc.o_pos;
   std::vector<double> scr(8 * BLK, 0.0);
   struct St { Wave Dc, Wp, Hr, Lc, Ln, Sn, Hc, Hn, Sh; int pend; bool ok; } st[4];
@@ -441,11 +438,17 @@ int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
   auto barrier = [&]() { std::fill(wr.begin(), wr.end(), -1); std::fill(rd.begin(), rd.end(), 0); };
   auto SB = [&](int b) { return &S[(size_t)b * BLK]; };
   auto SC = [&](int b) { return &scr[(size_t)b * BLK]; };
+  for (int pi = 0; pi < (int)oc.pairs.size(); pi++) {      // the twisted pairs one after the other (kernel_onchip.hpp oc_ldl); the helpers' hub sums carry across
+  const int rec = oc.o_pair + 12 * pi;
+  const int LE = tab[rec], LF = tab[rec + 1];
+  const bool junc = tab[rec + 4] && LF > 0;
+  const int Sph = junc ? std::max(LE + 1, LF) : LE;
+  for (auto &x : st) { x.Dc = x.Wp = x.Hr = x.Lc = x.Ln = x.Sn = x.Hc = x.Hn = zero(); x.pend = -1; }
   const int nph = HUB ? Sph + 1 : Sph;
   for (int s = -1; s < nph; s++) {                       // s = -1: the fetches ahead of the first phase
     for (int wid = 0; wid < 4; wid++) {
       const int ch = wid & 1; const bool helper = wid >= 2;
-      const int L = ch == 0 ? LE : LF, cb = ch == 0 ? oc.o_chainE : oc.o_chainF;
+      const int L = ch == 0 ? LE : LF, cb = ch == 0 ? tab[rec + 2] : tab[rec + 3];
       auto step_of = [&](int q) -> int { if (q < 0) return -1; if (ch == 0) return q < LE ? q : -1; if (q < LF - 1) return q; return (q == Sph - 1 && LF > 0) ? LF - 1 : -1; };
       auto gsv = [&](int k) { return pt[5 * tab[cb + 2 * k]]; };
       auto csv = [&](int k) { return pt[5 * tab[cb + 2 * k] + 1]; };
@@ -506,6 +509,8 @@ int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
     if (s >= 0) barrier();                               // (no barrier between the fetches ahead and phase 0)
   }
   for (int wid = 0; wid < 2; wid++) if (st[wid].pend >= 0) { touch(wid, st[wid].pend, true); stA(SB(st[wid].pend), st[wid].Wp); }
+  barrier();
+  }
   bool ok = st[0].ok && st[1].ok;
   if (HUB) {
     stD(SC(6), st[2].Sh); stD(SC(7), st[3].Sh);
@@ -521,15 +526,26 @@ int emu_oc_ldl(const OcPlan &oc, std::vector<double> &S, bool HUB) {
 
 // nw = 4: the two-workgroups-per-CU instances (twisted order, chains of at most 17 positions); nw = 8: the long-chain instances (padded
 // twist -- ordering 3 --, chains of any length, zyg: z and y in the slab for the LDS figure)
+// (ordering 4: the dissected order -- separators of the chain in the hub block, several twisted pairs; info[2] then reports the number of pairs)
+static int plan_execute_oc_impl(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw, int NG, int NH, int ldl, int zyg, int ordering,
+                                const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info);
 extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw, int NG, int NH, int ldl, int zyg,
                                   const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  return plan_execute_oc_impl(n, m, Pp, Pi, Ap, Ai, nw, NG, NH, ldl, zyg, nw == 8 ? 3 : 2, Pval, Aval, rho, sigma, rhs, sol, info);
+}
+extern "C" int plan_execute_oc_dissected(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH, int ldl,
+                                         const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  return plan_execute_oc_impl(n, m, Pp, Pi, Ap, Ai, 8, NG, NH, ldl, 0, 4, Pval, Aval, rho, sigma, rhs, sol, info);
+}
+static int plan_execute_oc_impl(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw, int NG, int NH, int ldl, int zyg, int ordering,
+                                const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
   if (nw != 4 && nw != 8) return 1;
-  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, nw == 8 ? 3 : 2, nw == 8 ? 2 : 1);
-  if (!pl.error.empty()) return 1;
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, ordering, nw == 8 ? 2 : 1);
+  if (!pl.error.empty()) return ordering == 4 ? 5 : 1;
   ResPlan rp = build_res_plan(pl, nw, false);
   OcPlan oc = build_oc_plan(pl, nw, 1 << 20, NG, NH, nw == 8 ? 64 : OC_CHAIN_SHORT);
   if (info) { info[0] = oc.nbc; info[1] = oc.has_hub; info[2] = oc.junc; info[3] = oc.nlds; info[4] = oc.nhr; info[5] = oc.ok ? lds_bytes_oc(pl, rp, oc, zyg != 0) : 0;
-              info[6] = (long)oc.chainE.size(); info[7] = (long)oc.chainF.size(); }
+              info[6] = (long)oc.chainE.size(); info[7] = (long)oc.chainF.size(); if (ordering == 4) info[2] = (long)oc.pairs.size(); }
   if (!oc.ok) return 5;
   // ---- factor (as plan_execute_res: assembly + level-parallel LDL')
   std::vector<double> vA, vAt, vP;
@@ -599,13 +615,22 @@ extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, co
     }
   }
   // ---- oc_solve
-  std::vector<double> R((size_t)pl.npad + oc_rext(nw), 0.0);
+  const int np = (int)oc.pairs.size();
+  if (2 * np > nw) return 1;
+  std::vector<double> R((size_t)pl.npad + oc_rext(nw, np), 0.0);
   for (int j = 0; j < n; j++) R[pl.pos[j]] = rhs[j];
   double *EXT = &R[pl.npad];
-  const int LE = tab[0], LF = tab[1], H = oc.nbc, f = (oc.junc && LF > 0) ? tab[oc.o_chainF + 2 * (LF - 1)] : -1;
+  const int H = oc.nbc;
+  // chain waves 2 i (E) and 2 i + 1 (F) walk pair i; its junction term waits in vector block 0 (pair 0) / nw + 1 + i behind the solve vector
+  auto P_LE = [&](int i) { return tab[oc.o_pair + 12 * i + 5]; };
+  auto P_LF = [&](int i) { return tab[oc.o_pair + 12 * i + 6]; };
+  auto P_cb = [&](int i, int role) { return tab[oc.o_pair + 12 * i + 7 + role]; };
+  auto P_junc = [&](int i) { return tab[oc.o_pair + 12 * i + 4]; };
+  auto P_f = [&](int i) { return (P_junc(i) && P_LF(i) > 0) ? tab[P_cb(i, 1) + 2 * (P_LF(i) - 1)] : -1; };
+  auto P_xs = [&](int i) { return i == 0 ? 0 : nw + 1 + i; };
   const bool HUB = NH > 0;
   if (HUB != (oc.has_hub != 0)) return 5;
-  std::vector<int> wr(pl.nb + nw + 2, -1), rd(pl.nb + nw + 2, 0);      // hazard tracking per vector block within a phase
+  std::vector<int> wr(pl.nb + nw + 2 + np, -1), rd(pl.nb + nw + 2 + np, 0);      // hazard tracking per vector block within a phase
   bool hazard = false;
   auto touch = [&](int w, int blk, bool write) {
     if (wr[blk] >= 0 && wr[blk] != w) hazard = true;
@@ -617,8 +642,9 @@ extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, co
   auto bc4 = [](const Wave1 &r) { Wave x; for (int l = 0; l < 64; l++) for (int K = 0; K < 4; K++) x.v[l][K] = r.v[(l & 0x33) | (K << 2)]; return x; };
   auto ldE4 = [](const double *vec, int p) { Wave1 r; for (int l = 0; l < 64; l++) r.v[l] = vec[BS * p + 4 * ((l >> 2) & 3) + (l >> 4)]; return r; };
   bool quads1 = true;
-  for (int w = 0; w < 2; w++) {
-    const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
+  for (int w = 0; w < 2 * np; w++) {
+    const int pi = w >> 1, role = w & 1;
+    const int len = role == 0 ? P_LE(pi) : P_LF(pi), cb = P_cb(pi, role);
     if (len == 0) continue;
     int e = 0; touch(w, tab[cb], false);
     Wave x = ldB4(R.data(), tab[cb]);
@@ -631,11 +657,11 @@ extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, co
       quads1 = stB4(R.data(), pn, c) && quads1;
       x = bc4(c); e = k + 1;
     }
-    if (w == 0 && oc.junc) { Wave1 c = zero1(); mv4(ldF4(&BL[(size_t)tab[cb + 2 * e + 1] * BLK]), x, c); touch(w, ext0, true); quads1 = stB4(EXT, 0, c) && quads1; }
+    if (role == 0 && P_junc(pi)) { Wave1 c = zero1(); mv4(ldF4(&BL[(size_t)tab[cb + 2 * e + 1] * BLK]), x, c); touch(w, ext0 + P_xs(pi), true); quads1 = stB4(EXT, P_xs(pi), c) && quads1; }
   }
   if (!quads1) return 1;
   barrier();
-  if (f >= 0) { const int w = f & (nw - 1); touch(w, f, false); touch(w, ext0, false); Wave t = add(ldB(R.data(), f), ldB(EXT, 0)); touch(w, f, true); stB(R.data(), f, t); }
+  for (int pi = 0; pi < np; pi++) { const int f = P_f(pi); if (f >= 0) { const int w = f & (nw - 1); touch(w, f, false); touch(w, ext0 + P_xs(pi), false); Wave t = add(ldB(R.data(), f), ldB(EXT, P_xs(pi))); touch(w, f, true); stB(R.data(), f, t); } }
   std::vector<Wave> xh(nw, zero());
   std::vector<Wave1> xhd(nw, zero1());
   bool quads = true;
@@ -673,11 +699,12 @@ extern "C" int plan_execute_oc_nw(int n, int m, const int *Pp, const int *Pi, co
   barrier();
   if (HUB) { touch(nw - 1, H, true); quads = stB4(R.data(), H, xhd[nw - 1]) && quads; }
   if (!quads) return 1;
-  for (int w = 0; w < 2; w++) {
-    const int len = w == 0 ? LE : LF, cb = w == 0 ? oc.o_chainE : oc.o_chainF;
+  for (int w = 0; w < 2 * np; w++) {
+    const int pi = w >> 1, role = w & 1, f = P_f(pi);
+    const int len = role == 0 ? P_LE(pi) : P_LF(pi), cb = P_cb(pi, role);
     if (len == 0) continue;
     int k = len - 2; Wave x;
-    if (w == 0 && oc.junc) { touch(w, f, false); x = ldB4(R.data(), f); k = len - 1; } else { touch(w, tab[cb + 2 * (len - 1)], false); x = ldB4(R.data(), tab[cb + 2 * (len - 1)]); }
+    if (role == 0 && P_junc(pi)) { touch(w, f, false); x = ldB4(R.data(), f); k = len - 1; } else { touch(w, tab[cb + 2 * (len - 1)], false); x = ldB4(R.data(), tab[cb + 2 * (len - 1)]); }
     for (; k >= 0; k--) {
       const int p = tab[cb + 2 * k], slot = tab[cb + 2 * k + 1];
       touch(w, p, false);
