@@ -227,6 +227,49 @@ def test_onchip_long_chain_plan_emulated(built, name, N, inst, expect, ldl):
         assert _run_oc(ls)[0] == 5                         # ... and the four-wave plan does not take it
 
 
+def _run_oc8_dissected(ls, NG, NH, b=0, seed=0, ldl=1):
+    """ordering 4 (plan.hpp build_plan: separators of the stage chain in the hub block, several twisted pairs) through the same emulation"""
+    L = C.CDLL(SO)
+    L.plan_execute_oc_dissected.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 3
+    rng = np.random.default_rng(seed)
+    n, m = ls.n, ls.m
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(8, np.int64)
+    Pv = np.ascontiguousarray(np.broadcast_to(ls.P, (ls.batch, len(ls.Pi)))[b]); Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[b])
+    rc = L.plan_execute_oc_dissected(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), NG, NH, ldl, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
+    if rc == 0:
+        ref = np.linalg.solve(M, rhs)
+        assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
+    return rc, dict(nbc=info[0], has_hub=info[1], npairs=info[2], nlds=info[3], nhr=info[4], lds=info[5], LE=info[6], LF=info[7])
+
+
+@pytest.mark.parametrize("name,N,inst,expect", [("cartpole", 100, (4, 4), dict(nbc=32, has_hub=1, npairs=4, nlds=29, LE=3, LF=5)),        # BASELINE config 4: 3 separators of 4 states beside the 4 parameters
+                                                ("cartpole", 150, (7, 7), dict(nbc=48, npairs=4, LE=5, LF=7)), ("cartpole", 60, (4, 4), dict(nbc=20, npairs=4)),
+                                                ("double_integrator", 100, (4, 4), dict(nbc=20, npairs=4))])
+@pytest.mark.parametrize("ldl", [0, 1])
+def test_onchip_dissected_plan_emulated(built, name, N, inst, expect, ldl):
+    """the dissected order: where the hub block has room, separators of the stage chain join the hub and the chain falls into segments, each a twisted pair
+    of short chains that chain waves 2 i, 2 i + 1 walk in the solve and the factorisation takes one after the other -- factor (level-parallel or the emulated
+    oc_ldl) and solve, lane-accurately, against dense linear algebra, with the hazard checks of the other emulations; no block more than the twisted order has"""
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    rc, info = _run_oc8_dissected(ls, *inst, b=1, ldl=ldl)
+    assert rc == 0, (rc, info)
+    for k, v in expect.items():
+        assert info[k] == v, (k, info)
+    assert info["lds"] <= 160 * 1024
+    rc0, info0 = _run_oc8(ls, *inst, 0, b=1, ldl=ldl)
+    assert rc0 == 0 and info["nlds"] <= info0["nlds"] and info["LF"] < info0["LF"] / 2
+
+
+def test_dissected_order_needs_room_in_the_hub(built):
+    """the quadrotor's 12 parameters leave 4 places in the hub block, its separators are 12 states: the order does not apply (mpcqp_create keeps the padded twist)"""
+    mdl, ls, _ = models.make_workload("quadrotor", 1, N=50)
+    assert _run_oc8_dissected(ls, 7, 7)[0] == 5
+
+
 @pytest.mark.parametrize("name,N,order,ntile", [("quadrotor", 20, 2, 19), ("quadrotor", 50, 3, 49), ("quadrotor", 10, 2, 9), ("cartpole", 100, 3, 0), ("double_integrator", 20, 2, 0)])
 def test_tile_plan_products(built, name, N, order, ntile):
     """dense tiles of A for the iteration's sweeps (plan.hpp build_tile_plan; opt-in MPCQP_TILES=1): every entry of A exactly once in a tile or
