@@ -48,7 +48,7 @@ def onchip_rooflines(pinfo, ocinfo, n, m, batch, iters_mean, kernel_ms):
     cycles_per_qp = kernel_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9 * min(resident, batch) / batch
     stages = 2 * max(ocinfo["chain_e"], ocinfo["chain_f"])
     dep = iters_mean * stages * 4 * MFMA_F64_4X4_DEP_CYCLES
-    return lds, {"value": dep / cycles_per_qp, "dependent_mfma_cycles_per_admm_iter": stages * 4 * MFMA_F64_4X4_DEP_CYCLES, "chain_positions": max(ocinfo["chain_e"], ocinfo["chain_f"]),
+    return lds, {"value": dep / cycles_per_qp, "dependent_mfma_cycles_per_admm_iter": stages * 4 * MFMA_F64_4X4_DEP_CYCLES, "chain_positions": max(ocinfo["chain_e"], ocinfo["chain_f"]), "chain_pairs": ocinfo.get("chain_pairs", 1),
                  "resident_cycles_per_qp": cycles_per_qp, "note": "chains of the forward and backward sweep: 4 dependent v_mfma_f64_4x4x4_4b_f64 per position at %d cycles, over kernel time x QPs resident per CU (%d) at %.1f GHz" % (MFMA_F64_4X4_DEP_CYCLES, 2 if nw == 4 else 1, SHADER_CLOCK_GHZ)}
 
 

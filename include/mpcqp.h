@@ -206,7 +206,7 @@ int mpcqp_plan_info(const mpcqp_handle *h, long *info16);
  * the pattern has an arrow head (the parameter block), lengths of the two elimination chains (the critical path of each triangular sweep: one
  * dependent 16 x 16 mat-vec per position), factor blocks resident in LDS, positions per wave, hub blocks per wave in registers, and -- two-kernel
  * form -- the number of {re-factorisation, iteration} launch pairs queued behind a solve for adaptive-rho steps (0 = single kernel);
- * info[8..10]: 64-lane ELL slots of A (by row), A' (by variable) and P that a sweep walks; info[11] reserved.  No reference counterpart (the
+ * info[8..10]: 64-lane ELL slots of A (by row), A' (by variable) and P that a sweep walks; info[11]: twisted pairs of chains (1: plain or twisted order; more: the dissected order, whose chains info[2], info[3] describe pair 0).  No reference counterpart (the
  * reference's instruments are the two timers of SQPOptimizationSolver.cpp:133-164). */
 int mpcqp_oc_info(const mpcqp_handle *h, long *info12);
 

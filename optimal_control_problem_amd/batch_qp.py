@@ -216,7 +216,7 @@ class BatchQP:
         a = np.zeros(12, dtype=np.int64)
         _lib.check(_lib.lib().mpcqp_oc_info(self._h, a.ctypes.data))
         return dict(zip(["chain_blocks", "has_hub", "chain_e", "chain_f", "lds_blocks", "positions_per_wave", "hub_blocks_in_registers", "launch_pairs_for_rho_updates",
-                         "slots_A", "slots_At", "slots_P"], a.tolist()))
+                         "slots_A", "slots_At", "slots_P", "chain_pairs"], a.tolist()))
 
     def plan_info(self):
         a = np.zeros(16, dtype=np.int64)

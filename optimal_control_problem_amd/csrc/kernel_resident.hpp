@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(NW * WAVE, MINW) mpcqp_res_kernel(const DevPla
       TS(4);
       if constexpr (OC) {
 #ifdef MPCQP_TIMING
-        if constexpr (NW == 4 && !TL) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, oc_chain_info<NW>(oc, octab, wid, lane), ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
+        if constexpr (NW == 4 && !TL) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, ts_acc + 9);   // slots 9..11: F1, F2 + F3, B1 (B2 = the rest of the solve)
         else oc_solve_long<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch, oc_chain_info<NW>(oc, octab, wid, lane), ts_acc + 9);
 #else
         if constexpr (NW == 4 && !TL) oc_solve<NW, OCG, OCH, (OCH > 0)>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, octicket, iter, late_rows, idle_touch);

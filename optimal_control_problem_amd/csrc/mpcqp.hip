@@ -1152,7 +1152,7 @@ int mpcqp_oc_info(const mpcqp_handle *h, long *o) {
   o[8] = h->plan.A.slots(); o[9] = h->plan.At.slots(); o[10] = h->plan.P.slots();
   if (!h->oc) return MPCQP_OK;
   const OcPlan &p = h->ocplan;
-  o[0] = p.nbc; o[1] = p.has_hub; o[2] = (long)p.chainE.size(); o[3] = (long)p.chainF.size(); o[4] = p.nlds; o[5] = p.npw; o[6] = p.nhr; o[7] = h->split ? 1 + h->resume_rounds : 0;
+  o[0] = p.nbc; o[1] = p.has_hub; o[2] = (long)p.chainE.size(); o[3] = (long)p.chainF.size(); o[4] = p.nlds; o[5] = p.npw; o[6] = p.nhr; o[7] = h->split ? 1 + h->resume_rounds : 0; o[11] = (long)std::max<size_t>(1, p.pairs.size());
   return MPCQP_OK;
 }
 
