@@ -685,6 +685,41 @@ def test_resident_workgroups_draw_every_instance_once(built, monkeypatch):
         assert np.array_equal(host[k], ref[k]), k
 
 
+def test_dissected_order_nonconvex_instance_and_graph_replay(built, monkeypatch):
+    """the dissected order of the eight-wave instances (separators of the stage chain in the hub block, several twisted pairs; plan.hpp ordering 4): an instance
+    whose P is indefinite is reported non-convex by the pair-by-pair factorisation while its neighbours solve as the oracle does, the padded twist gives the
+    same statuses and iteration counts, and a solve captured in a HIP graph (its ticket counters are zeroed by a memset node) replays bit for bit"""
+    import torch
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("cartpole", 300, N=100)
+    monkeypatch.setenv("MPCQP_VARIANT", "oc8")
+    P = np.array(np.broadcast_to(ls.P, (ls.batch, ls.P.shape[-1]))); P[7] = -np.abs(P[7]) - 1.0
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert qp.plan_info()["variant"] == 208 and qp.oc_info()["chain_pairs"] == 4 and qp.plan_info()["ordering"] == 4
+    qp.update(P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get()
+    assert got["status"][7] == 9 and np.isnan(got["x"][7]).all() and (np.delete(got["status"], 7) == 1).all()
+    ref = problems.oracle_solve(ls)
+    keep = np.arange(ls.batch) != 7
+    assert (got["iters"][keep] == ref["iters"][keep]).all()
+    assert np.abs(got["x"][keep] - ref["x"][keep]).max() <= 1e-6 * max(1.0, np.abs(ref["x"][keep]).max())
+    s = torch.cuda.Stream(); g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        qp.solve(stream=s.cuda_stream); s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            qp.solve(stream=s.cuda_stream)
+        g.replay(); s.synchronize()
+    again = qp.get()
+    for k in ("x", "y", "z", "status", "iters"):
+        assert np.array_equal(again[k], got[k], equal_nan=True), k
+    qp.close()
+    monkeypatch.setenv("MPCQP_NO_DISSECT", "1")
+    q0 = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    assert q0.oc_info()["chain_pairs"] == 1 and q0.plan_info()["ordering"] == 2      # (the padded twist reports as the twisted order)
+    q0.update(P, ls.q, ls.A, ls.l, ls.u); q0.solve(); tw = q0.get(); q0.close()
+    assert np.array_equal(tw["status"], got["status"]) and np.array_equal(tw["iters"], got["iters"])
+    assert np.nanmax(np.abs(tw["x"] - got["x"])) < 1e-7
+
+
 @pytest.mark.parametrize("name,N,B", [("quadrotor", 50, 40), ("quadrotor", 100, 12), ("cartpole", 100, 30)])
 def test_long_horizons_vs_oracle(built, name, N, B):
     """long horizons run the global-block kernels, the longest ones with z and y in the slab as well (one more workgroup per
