@@ -410,7 +410,17 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
     else if (w == 3) { oc_touch_pinned(lb, (long)mpad * 8, lane); oc_touch_pinned(ub, (long)mpad * 8, lane); oc_touch_pinned(valAt, pl.At.entries * 8, lane); }
   };
   [[maybe_unused]] const OcChain occ = oc_chain_info<NW>(oc, octab, wid, lane);      // (after the tables are in LDS)
-  const int myAt = oc_my_chunks<NW>(TL ? oc.tl.Atr_off : pl.At.chunk_off, pl.At.nchunks, wid, lane), myA = oc_my_chunks<NW>(TL ? oc.tl.Ar_off : pl.A.chunk_off, pl.A.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
+  const int myAt = oc_my_chunks<NW>(TL ? oc.tl.Atr_off : pl.At.chunk_off, pl.At.nchunks, wid, lane);      // (a wave has at most 32 chunks of either: the host checks)
+  int myA = oc_my_chunks<NW>(TL ? oc.tl.Ar_off : pl.A.chunk_off, pl.A.nchunks, wid, lane);
+  [[maybe_unused]] int myAid = wid + lane * NW;      // lane k: the wave's k-th row chunk of A
+  if constexpr (NW == 8 && !TL) {
+    if (oc.a_assign) {
+      const int ck = oc.a_assign[wid * 32 + min(lane >> 1, 31)];
+      myA = (ck >= 0 && ck < pl.A.nchunks) ? pl.A.chunk_off[ck + (lane & 1)] : 0;
+      myAid = oc.a_assign[wid * 32 + min(lane, 31)];
+    }
+    if (myAid >= pl.A.nchunks || lane >= 32) myAid = -1;
+  }
   // TL: this wave's tile records, read once into the lanes of registers (picked out with v_readlane inside the sweeps: no table access in front of a chunk's loads).
   //   A' sweep, lane 4 k + u: the tile of column block u of the wave's k-th chunk (or the zero tile) and the first of its sixteen rows of w
   //   A sweep,  lane 8 k + u: the u-th tile with a row in the wave's k-th chunk {tile, column block, first row, rows}; lane k of taCnt: how many; bit k of
@@ -519,8 +529,12 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
       {
         // ztilde = A xtilde fused with relaxation, projection onto [l, u], dual update and w = rho z - y.  l, u, z, y of the row are fetched before
         // the row sum is accumulated.
-        for (int ch = wid; ch < pl.A.nchunks; ch += NW) {
-          const int i = ch * WAVE + lane, k = (ch - wid) / NW;
+        // (eight-wave instances: the wave's row chunks come from a list the host balanced by load batches -- ten wide chunks of the quadrotor's N=50 on eight
+        // waves left two waves with seven round trips where six are enough; rows are independent, any wave may take any chunk.  Four waves: chunk wid + k NW)
+        constexpr bool LPT = NW == 8 && !TL;
+        for (int kq = 0, ch = LPT ? __builtin_amdgcn_readlane(myAid, 0) : wid; LPT ? (kq < 32 && ch >= 0) : ch < pl.A.nchunks;
+             ++kq, ch = LPT ? __builtin_amdgcn_readlane(myAid, min(kq, 31)) : ch + NW) {
+          const int i = ch * WAVE + lane, k = LPT ? kq : (ch - wid) / NW;
           const double lo = lb[i], up = ub[i];
           const double zo = i < mpad ? cx.Z[i] : 0.0, yo = i < mpad ? cx.Y[i] : 0.0;
           double zt;

@@ -31,6 +31,7 @@ struct DevTile {
 struct DevOc {
   int nbc, has_hub, junc, npw, nhr, nlds, ntab;
   int o_chainE, o_chainF, o_pos, o_fill, ghub_slot, ghub_src;
+  const int *a_assign;  // eight-wave instances: [8][32] row chunks of A per wave for the iteration's A sweep, balanced by load batches (-1: none); NULL = chunk wid + 8 k
   int npair, o_pair;   // twisted pairs of chains (plan.hpp OcPlan::pairs) and their records in tab: {LE, LF, oE, oF, junc, sLE, sLF, soE, soF, -, -, -}
   int nfill, o_s, o_dbl, ndbl, o_pp;   // LDS slots filled from the slab; the chains the solve walks; its double stages and their product blocks (plan.hpp oc_add_doubles)
   int at_poll, at_free;   // chunks of A' whose rows the iteration computes during the chain phase instead of before it (-1: none); see oc_solve

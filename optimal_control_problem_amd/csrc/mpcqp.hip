@@ -562,6 +562,21 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       dd.a_lds = sh.a; dd.p_lds = sh.p; dd.ix16 = sh.ix16; dd.zpad = sh.zpad;
       ds.stage = sh.stage; h->setup_nw = 4; h->lds_setup = sh.bytes;
       const long vecs = vec + sh.zpad;
+      if (h->oc8 && !h->vtiles && !getenv("MPCQP_NO_ABALANCE")) {
+        // row chunks of A to waves by longest-processing-time over their load batches (a batch = one round trip to memory; plan.hpp ell_batches8)
+        std::vector<int> assign(8 * 32, -1), load(8, 0), cnt(8, 0), order_(pq.A.nchunks);
+        for (int c = 0; c < pq.A.nchunks; c++) order_[c] = c;
+        auto batches = [&](int c) { return ell_batches8(pq.A.chunk_off[c + 1] - pq.A.chunk_off[c]); };
+        std::stable_sort(order_.begin(), order_.end(), [&](int a, int b) { return batches(a) > batches(b); });
+        bool okA = true;
+        for (int c : order_) {
+          int w = 0;
+          for (int v = 1; v < 8; v++) if (load[v] < load[w] || (load[v] == load[w] && cnt[v] < cnt[w])) w = v;
+          if (cnt[w] >= 32) { okA = false; break; }
+          assign[w * 32 + cnt[w]++] = c; load[w] += std::max(1, batches(c));
+        }
+        if (okA) UP(upload(h, assign, &h->doc.a_assign));
+      }
       if (h->oc8) {
         int nb = 0; h->qslots = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, oc_admm_of(h, false), h->variant * WAVE, (size_t)h->lds) == hipSuccess && nb > 0) {
