@@ -540,17 +540,30 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const long vec = 2L * pq.npad + oc_rext(h->variant, std::max<int>(1, (int)h->ocplan.pairs.size())) + pq.mpad + pq.npad + 16L * 4 + 16 + 16L * 4;      // x, r; w; y (an n-vector here); the reduction scratch
       const long tabw = ((long)h->ocplan.o_pos + 1) / 2 + 4 + ((long)pq.A.nchunks + pq.At.nchunks + pq.P.nchunks + 3 + 1 + 1) / 2;
       const long cu = 160L * 1024, nA = (long)pq.A.entries(), nP = (long)pq.P.entries();
-      struct Shape { long stage, bytes; int a, p, ix16, zpad; bool fits; };
+      struct Shape { long stage, bytes; int a, p, ix16, zpad, ixo_a, ixo_p; bool fits; };
+      const long zoff = 2L * pq.npad + oc_rext(h->variant, std::max<int>(1, (int)h->ocplan.pairs.size()));      // (the z region starts behind x and r: kernel_oc_split.hpp oc_lds<NW, true>)
       auto shape = [&](const long cap_bytes) {
         const long cap = cap_bytes / 8;
-        Shape r{scratch, 0, 0, 0, 0, 0, false};
+        Shape r{scratch, 0, 0, 0, 0, 0, 0, 0, false};
         if (std::max(scratch, nA) + vec + tabw <= cap) { r.stage = std::max(scratch, nA); r.a = 1; }
         if (r.a && std::max(scratch, nA + nP) + vec + tabw <= cap) { r.stage = std::max(scratch, nA + nP); r.p = 1; }
         r.stage = (r.stage + 15) / 16 * 16;
         long total = r.stage + vec + tabw;
-        if (r.a && r.p && pq.npad < 65536 && !getenv("MPCQP_NO_IX16")) {      // (the ten Ruiz passes then gather without a round trip to the L2 in front of every batch)
-          const long zA = (nA / 4 + 15) / 16 * 16, zAP = ((nA + nP) / 4 + 15) / 16 * 16;
+        const long zA = (nA / 4 + 15) / 16 * 16, zP = (nP / 4 + 15) / 16 * 16, zAP = ((nA + nP) / 4 + 15) / 16 * 16;
+        const bool ix_ok = pq.npad < 65536 && !getenv("MPCQP_NO_IX16");
+        if (r.a && r.p && ix_ok) {      // (the ten Ruiz passes then gather without a round trip to the L2 in front of every batch)
           if (total + zAP <= cap) { r.ix16 = 3; r.zpad = (int)zAP; } else if (total + zA <= cap) { r.ix16 = 1; r.zpad = (int)zA; }
+          r.ixo_a = (int)(4 * (r.stage + zoff)); r.ixo_p = r.ixo_a + (int)nA;
+          total += r.zpad;
+        } else if (!r.a && ix_ok) {
+          // values in the slab: the index tables alone (a quarter less to read per pass, the gathers' addresses from LDS) -- one of them in the factorisation's
+          // scratch, which is idle until the factorisation starts, the other in the z region where that does not cost a workgroup per CU
+          const bool a_scr = zA <= r.stage, p_scr = zP <= r.stage;
+          auto z_fits = [&](long z) { return total + z <= cap && cu / ((total + z) * 8) == cu / (total * 8); };
+          if (a_scr && z_fits(zP)) { r.ix16 = 3; r.ixo_a = 0; r.zpad = (int)zP; r.ixo_p = (int)(4 * (r.stage + zoff)); }
+          else if (p_scr && z_fits(zA)) { r.ix16 = 3; r.ixo_p = 0; r.zpad = (int)zA; r.ixo_a = (int)(4 * (r.stage + zoff)); }
+          else if (a_scr) { r.ix16 = 1; r.ixo_a = 0; }
+          else if (z_fits(zA)) { r.ix16 = 1; r.zpad = (int)zA; r.ixo_a = (int)(4 * (r.stage + zoff)); }
           total += r.zpad;
         }
         r.bytes = total * 8; r.fits = total <= cap;
@@ -559,7 +572,7 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       Shape sh = shape(cu / 2);
       if (const char *e = getenv("MPCQP_SETUP_CAP")) sh = shape(atol(e));
       else { const Shape s3 = shape(cu / 3); if (s3.fits && (s3.a || !(sh.a && sh.p))) sh = s3; }
-      dd.a_lds = sh.a; dd.p_lds = sh.p; dd.ix16 = sh.ix16; dd.zpad = sh.zpad;
+      dd.a_lds = sh.a; dd.p_lds = sh.p; dd.ix16 = sh.ix16; dd.zpad = sh.zpad; dd.ixo_a = sh.ixo_a; dd.ixo_p = sh.ixo_p;
       ds.stage = sh.stage; h->setup_nw = 4; h->lds_setup = sh.bytes;
       const long vecs = vec + sh.zpad;
       if (h->oc8 && !h->vtiles && !getenv("MPCQP_NO_ABALANCE")) {
