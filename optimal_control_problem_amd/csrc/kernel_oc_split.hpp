@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_setup_kernel(const DevP
 // RF = 1: an adaptive-rho step re-factorises in place (the last launch of a solve); RF = 0: the instance leaves for the set-up kernel's resume mode
 // TL: the two sweeps of the iteration on dense tiles of A + remainder ELL layouts (experiment; below)
 // One instance; called once per workgroup (a grid of `count` workgroups) or, with DevIO.queue set, again and again by a resident workgroup that draws tickets.
-template <int NW, int OCG, int OCH, int RF, bool TL>
+template <int NW, int OCG, int OCH, int RF, bool TL, bool PAIRS>
 __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs, const mpcqp_settings &st, const DevIO &io, const DevOc &oc, double *lds, const int b, const int wid, const int lane) {
   constexpr int NT = NW * WAVE;
   [[maybe_unused]] constexpr int OCU = NW == 4 ? 16 : 8;      // ELL slots in flight per lane (eight waves split the chunks further and hold more resident blocks)
@@ -520,7 +520,7 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
       unsigned long long *const stamps = nullptr;
 #endif
 #ifndef MPCQP_VALU_CHAINS     // (experiment, -DMPCQP_VALU_CHAINS: the chains on the vector ALUs too -- oc_solve_v: parity-green, 4 - 20 % slower)
-      if constexpr (NW == 4) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
+      if constexpr (NW == 4 && !PAIRS) oc_solve<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, stamps);
       else oc_solve_long<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, nullptr, iter, late_rows, idle_touch, occ, stamps);
 #else
       oc_solve_v<NW, OCG, OCH, HUB>(oc, octab, ocBL, cx.R, npad, ocl, ocw, ocG, ocHF, ocHT, wid, idle_touch, stamps);
@@ -659,14 +659,15 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
 // the iteration kernel took 23.5 ms in batch order and 21.0 ms with the longest-first order of a repeated solve.  With DevIO.queue the grid is as many
 // workgroups as the GPU holds at once, and each draws the next instance from ONE counter until none is left: the same batch order, balanced to within one
 // instance.  (Every wave reaches the exit: the ticket is read behind a barrier, uniformly.)
-template <int NW, int OCG, int OCH, int RF, bool TL = false>
+// PAIRS: a four-wave instance whose plan has two twisted pairs (the dissected order): the solve of the eight-wave instances' text, chain waves 0 .. 3
+template <int NW, int OCG, int OCH, int RF, bool TL = false, bool PAIRS = false>
 __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPlan pl, const DevRes rs, const mpcqp_settings st, const DevIO io, const DevOc oc) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63;
   int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (NW == 4) wid = oc_wave_role4(lds, wid, lane, io.no_remap);
   if constexpr (NW != 8) {      // (the four-wave instances, two workgroups per CU, keep a grid of one workgroup per instance: measured below)
-    oc_admm_one<NW, OCG, OCH, RF, TL>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x), wid, lane);
+    oc_admm_one<NW, OCG, OCH, RF, TL, PAIRS>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[blockIdx.x] : (int)blockIdx.x), wid, lane);
     return;
   }
   const OcLds<NW> L = oc_lds<NW>(lds, pl, rs, oc);
@@ -700,7 +701,7 @@ __global__ void __launch_bounds__(NW * WAVE, 2) mpcqp_oc_admm_kernel(const DevPl
     // this loop it stays live across the whole body: 240 B of scratch in an instance that had none)
     int lane_q = lane, wid_q = wid;
     asm volatile("" : "+v"(lane_q), "+s"(wid_q));
-    oc_admm_one<NW, OCG, OCH, RF, TL>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[t] : t), wid_q, lane_q);
+    oc_admm_one<NW, OCG, OCH, RF, TL, PAIRS>(pl, rs, st, io, oc, lds, __builtin_amdgcn_readfirstlane(io.order ? io.order[t] : t), wid_q, lane_q);
     bsync<NW>();      // (LDS is this instance's until every wave is through with it -- and the ticket until every wave has read it)
   }
 }

@@ -26,4 +26,5 @@ MPCQP_HIDDEN const void *mpcqp_kernel_oc_mono_r1(int nw, int ng, int nh, bool ti
 MPCQP_HIDDEN const void *mpcqp_kernel_oc_setup(int nw, bool hub, bool reuse);
 MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm(int nw, int ng, int nh);        // leaves for a re-factorisation
 MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm_rf(int nw, int ng, int nh);
+MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm_p4(int rf);                      // four waves, two twisted pairs of chains (dissected order)
 MPCQP_HIDDEN const void *mpcqp_kernel_oc_admm_tl(int nw, int ng, int nh);     // sweeps on dense tiles of A (experiment, MPCQP_VTILES=1)     // re-factorises in place (the last launch of a solve)

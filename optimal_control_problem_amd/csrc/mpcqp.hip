@@ -165,6 +165,7 @@ static const void *res_kernel_of(const mpcqp_handle *h, bool reuse) {
 static const void *oc_setup_of(const mpcqp_handle *h, bool reuse) { return mpcqp_kernel_oc_setup(h->setup_nw, h->ocplan.has_hub != 0, reuse); }
 static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
   const int nw = h->oc8 ? 8 : 4, ng = h->oc8 ? OC8_INST[h->oc8 - 1].ng : OC_NG, nh = !h->ocplan.has_hub ? 0 : h->oc8 ? OC8_INST[h->oc8 - 1].nh : OC_NH;
+  if (!h->oc8 && h->ocplan.pairs.size() > 1) return mpcqp_kernel_oc_admm_p4(rf ? 1 : 0);      // (four waves, two twisted pairs: its own instances)
   if (h->vtiles && !rf) return mpcqp_kernel_oc_admm_tl(nw, ng, nh);      // (the last launch of a solve, rf, runs the ELL sweeps: the set-up writes both forms)
   return rf ? mpcqp_kernel_oc_admm_rf(nw, ng, nh) : mpcqp_kernel_oc_admm(nw, ng, nh);
 }
@@ -370,11 +371,20 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       // on-chip mode: block tridiagonal + arrow patterns whose factor fits LDS + the registers of the instance at two workgroups per CU
       const ResPlan r4 = build_res_plan(p4, 4, false);
       h->oc = false;
-      const OcPlan o = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();
-      if (o.ok && lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX) {
+      OcPlan o = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();
+      bool dissected4 = false;
+      if (o.ok && o.has_hub && twist && !getenv("MPCQP_NO_DISSECT") && !getenv("MPCQP_OC_MONO") && !getenv("MPCQP_TILES") && !getenv("MPCQP_VTILES") && !getenv("MPCQP_DOUBLES")) {
+        // the dissected order with one separator: two twisted pairs on the four waves (plan.hpp build_plan ordering 4; its own kernel instances, two-kernel form only)
+        Plan pd = build_plan(n, m, Pp, Pi, Ap, Ai, 4, 2, 1);
+        if (pd.error.empty()) {
+          const OcPlan od = build_oc_plan(pd, 4, 1 << 20, OC_NG, OC_NH);
+          if (od.ok && od.pairs.size() == 2 && lds_bytes_oc(pd, build_res_plan(pd, 4, false), od) <= OC_LDS_MAX) { o = od; p4 = pd; dissected4 = true; }
+        }
+      }
+      if (o.ok && (dissected4 || lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX)) {
         h->ocplan = o; h->oc = true;
         // same ordering and blocks, ELL widths for this instance's 8 slots in flight (plan.hpp build_ell pad = 2)
-        if (!getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
+        if (!dissected4 && !getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
       }
       if (!h->oc && want == 4 && variant_request() && std::string(variant_request()) == "oc4")
         return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));

@@ -157,7 +157,7 @@ inline int block_fill(int nb, std::vector<std::set<int>> &pat) {
 }  // namespace detail
 
 // Build the plan. P: CSC n x n (entries with row > col ignored), A: CSC m x n.
-inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1, int pad4 = 0) {
+inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int force_ordering = -1, int pad4 = 0, int max_sep = 3) {
   Plan pl;
   pl.n = n; pl.m = m;
   if (n <= 0 || m < 0 || !Pp || !Ap) { pl.error = "invalid dimensions"; return pl; }
@@ -300,7 +300,7 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
     };
     int s0 = BS + 1;
     for (int c = BS; c + BS <= nonhub; c++) s0 = std::min(s0, (int)right_boundary(c).size());
-    const int want_sep = 3;
+    const int want_sep = std::max(1, max_sep);      // (three separators = four twisted pairs for eight waves; one = two pairs for four)
     const int S = (nhubv > 0 && nhubv < BS && s0 >= 1 && s0 <= BS) ? std::min(want_sep, (BS - nhubv) / s0) : 0;
     if (S >= 1 && nonhub >= 4 * BS * (S + 1)) {
       std::vector<char> is_sep(nonhub, 0);
@@ -990,7 +990,7 @@ inline OcPlan build_oc_plan(const Plan &pl, int nw, int max_lds_blocks, int max_
   // the dissected order, whose segments meet only in the hub (without a hub they would not be one matrix)
   std::map<int, std::vector<std::vector<int>>> by_end;
   for (int h : heads) { std::vector<int> c = walk(h); by_end[c.back()].push_back(c); }
-  if (by_end.size() > 1 && (!oc.has_hub || 2 * (int)by_end.size() > nw || nw != 8)) return oc;
+  if (by_end.size() > 1 && (!oc.has_hub || 2 * (int)by_end.size() > nw)) return oc;
   int total = 0;
   for (auto &kv : by_end) {
     std::vector<std::vector<int>> &cs = kv.second;

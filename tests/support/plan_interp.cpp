@@ -537,10 +537,14 @@ extern "C" int plan_execute_oc_dissected(int n, int m, const int *Pp, const int 
                                          const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
   return plan_execute_oc_impl(n, m, Pp, Pi, Ap, Ai, 8, NG, NH, ldl, 0, 4, Pval, Aval, rho, sigma, rhs, sol, info);
 }
+extern "C" int plan_execute_oc_dissected4(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int NG, int NH, int ldl,
+                                          const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
+  return plan_execute_oc_impl(n, m, Pp, Pi, Ap, Ai, 4, NG, NH, ldl, 0, 4, Pval, Aval, rho, sigma, rhs, sol, info);
+}
 static int plan_execute_oc_impl(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai, int nw, int NG, int NH, int ldl, int zyg, int ordering,
                                 const double *Pval, const double *Aval, const double *rho, double sigma, const double *rhs, double *sol, long *info) {
   if (nw != 4 && nw != 8) return 1;
-  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, ordering, nw == 8 ? 2 : 1);
+  Plan pl = build_plan(n, m, Pp, Pi, Ap, Ai, ordering, nw == 8 ? 2 : 1, nw == 8 ? 3 : 1);      // (dissected order: three separators for eight waves, one for four)
   if (!pl.error.empty()) return ordering == 4 ? 5 : 1;
   ResPlan rp = build_res_plan(pl, nw, false);
   OcPlan oc = build_oc_plan(pl, nw, 1 << 20, NG, NH, nw == 8 ? 64 : OC_CHAIN_SHORT);

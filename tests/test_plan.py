@@ -264,6 +264,38 @@ def test_onchip_dissected_plan_emulated(built, name, N, inst, expect, ldl):
     assert rc0 == 0 and info["nlds"] <= info0["nlds"] and info["LF"] < info0["LF"] / 2
 
 
+@pytest.mark.parametrize("name,N,expect", [("cartpole", 30, dict(nbc=10, npairs=2, LE=2, LF=3)), ("cartpole", 50, dict(nbc=16, npairs=2, LE=3, LF=5)),
+                                           ("double_integrator", 60, dict(nbc=12, npairs=2))])
+@pytest.mark.parametrize("ldl", [0, 1])
+def test_onchip_dissected_plan_four_waves_emulated(built, name, N, expect, ldl):
+    """the same order with ONE separator for the four-wave instances: two twisted pairs, chain waves 0 .. 3 (their own kernel instances run the eight-wave
+    instances' solve text); too short a chain, or no room in the hub, and the order does not apply"""
+    L = C.CDLL(SO)
+    L.plan_execute_oc_dissected4.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 3
+    mdl, ls, _ = models.make_workload(name, 2, N=N)
+    rng = np.random.default_rng(3)
+    n, m, b = ls.n, ls.m, 1
+    Pd, Ad = ls.dense(b)
+    Pd = np.triu(Pd) + np.triu(Pd, 1).T
+    rho = rng.choice([0.1, 100.0, 1e-6], size=m); sigma = 1e-6
+    M = Pd + sigma * np.eye(n) + Ad.T @ (rho[:, None] * Ad)
+    rhs = rng.normal(size=n); sol = np.zeros(n); info = np.zeros(8, np.int64)
+    Pv = np.ascontiguousarray(np.broadcast_to(ls.P, (ls.batch, len(ls.Pi)))[b]); Av = np.ascontiguousarray(np.broadcast_to(ls.A, (ls.batch, len(ls.Ai)))[b])
+    rc = L.plan_execute_oc_dissected4(n, m, _p(ls.Pp), _p(ls.Pi), _p(ls.Ap), _p(ls.Ai), 5, 3, ldl, _p(Pv), _p(Av), _p(rho), C.c_double(sigma), _p(rhs), _p(sol), _p(info))
+    assert rc == 0
+    ref = np.linalg.solve(M, rhs)
+    assert np.abs(sol - ref).max() / np.abs(ref).max() < 1e-9
+    got = dict(nbc=info[0], npairs=info[2], LE=info[6], LF=info[7])
+    for k, v in expect.items():
+        assert got[k] == v, (k, got)
+    assert info[5] <= 80 * 1024                                   # two workgroups per CU
+    for nm, NN in (("cartpole", 20), ("double_integrator", 40), ("quadrotor", 20)):
+        mdl, l2, _ = models.make_workload(nm, 1, N=NN)
+        Pv2 = np.ascontiguousarray(np.broadcast_to(l2.P, (1, len(l2.Pi)))[0]); Av2 = np.ascontiguousarray(np.broadcast_to(l2.A, (1, len(l2.Ai)))[0])
+        r2 = np.ones(l2.m); s2 = np.zeros(l2.n)
+        assert L.plan_execute_oc_dissected4(l2.n, l2.m, _p(l2.Pp), _p(l2.Pi), _p(l2.Ap), _p(l2.Ai), 5, 3, ldl, _p(Pv2), _p(Av2), _p(r2), C.c_double(sigma), _p(s2.copy()), _p(s2), _p(info)) == 5
+
+
 def test_dissected_order_needs_room_in_the_hub(built):
     """the quadrotor's 12 parameters leave 4 places in the hub block, its separators are 12 states: the order does not apply (mpcqp_create keeps the padded twist)"""
     mdl, ls, _ = models.make_workload("quadrotor", 1, N=50)
