@@ -85,28 +85,6 @@ __device__ __forceinline__ double opaque_uni(const double v) {
   lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// The re-factorisation of an adaptive-rho step, OUT OF LINE.  Inlined into the iteration kernel (as the single kernel has it) its register pressure
-// -- twelve operand tiles of the assembly, nine carried blocks of oc_ldl -- was behind 600 - 900 of that kernel's 700 - 1,100 spilled VGPRs although
-// it runs once in a hundred iterations, if at all.  As a function of its own it has its own allocation; the caller's resident blocks are dead across
-// the call (the factor is brought on chip again right after it).  It takes nothing that points into the kernel's argument segment (a kernel argument
-// whose address escapes into a call is copied to scratch, and the iteration would read it from there): the arguments it needs are read from a
-// copy in global memory that mpcqp_create uploads once, and the LDS carve-up is rebuilt from the LDS base.
-struct OcCold { DevPlan pl; DevRes rs; mpcqp_settings st; DevOc oc; };
-typedef __attribute__((address_space(3))) double lds_double;
-template <int NW, bool HUB>
-__device__ __attribute__((noinline)) bool oc_refactor_cold(const OcCold *__restrict__ g, lds_double *ldsp, double *ws, const int wid, const double rho) {
-  double *lds = (double *)ldsp;
-  const OcLds<NW> L = oc_lds<NW>(lds, g->pl, g->rs, g->oc);
-  RCtx cx;
-  cx.pl = &g->pl; cx.rs = &g->rs; cx.st = &g->st; cx.wid = wid; cx.lane = threadIdx.x & 63;
-  cx.fts[0] = cx.fts[1] = cx.fts[2] = cx.fts[3] = 0;
-  cx.ws = ws; cx.BL = ws + g->pl.o_Lf; cx.TMP = lds;
-  cx.X = L.X; cx.Q = L.Q; cx.R = L.R; cx.Z = L.Z; cx.Y = L.Y; cx.W = L.W; cx.RB = L.RB; cx.RED = L.RED;
-  cx.coA = L.co; cx.coAt = L.co + g->pl.A.nchunks + 1; cx.coP = L.co + g->pl.A.nchunks + g->pl.At.nchunks + 2;
-  cx.rho = rho; cx.c = 1.0; cx.cinv = 1.0; cx.unscale = 0;      // (the factorisation reads rho only)
-  return factorize_res<NW, (HUB ? 2 : 1)>(cx, &g->oc, L.octab, lds);
-}
-
 #ifdef MPCQP_TIMING
 // (the two kernels share a QP's row of 16 slots: each adds its own)
 #define TS_STORE_ADD(ptr, k0, k1) do { if (tid == 0 && (ptr)) { for (int k_ = (k0); k_ < (k1); k_++) (ptr)[16L * b + k_] += (long long)ts_acc[k_]; \
@@ -614,11 +592,7 @@ __device__ __forceinline__ void oc_admm_one(const DevPlan &pl, const DevRes &rs,
             }
             return;
           } else {
-#ifdef MPCQP_COLD_CALL
-            if (!oc_refactor_cold<NW, HUB>(reinterpret_cast<const OcCold *>(oc.cold), (lds_double *)lds, ws, wid, cx.rho)) { status = MPCQP_NON_CVX; break; }
-#else
             if (!factorize_res<NW, (HUB ? 2 : 1)>(cx, &oc, octab, ocBL)) { status = MPCQP_NON_CVX; break; }
-#endif
             oc_load_factor<NW, OCG, OCH>(oc, oc.tab, ws + pl.o_Lf, ocBL, ocl, ocG, ocHF, ocHT, wid, lane);
             rho_constants();
           }

@@ -39,7 +39,6 @@ struct DevOc {
   const int *tab;
   const int *asm_rec;   // [8 nblk] assembly recipe per block {terms, diagonal block row or -1, a0, b0, a1, b1, a2, b2} (T tile ids of the first three terms)
   DevTile tl;           // (the instances without tiles keep their argument layout)
-  const void *cold;     // two-kernel form: the kernel arguments once more in global memory (kernel_oc_split.hpp OcCold), for the out-of-line re-factorisation
   int resume;           // two-kernel form: this launch continues instances that left the iteration kernel for a re-factorisation (kernel_oc_split.hpp)
   int ixo_a, ixo_p;     // ... where those tables start, in 16-bit units from the LDS base (the z region; for shapes without staged values also the factorisation's scratch, idle until then)
   int ix16, zpad;       // set-up kernel (its own vector layout, kernel_oc_split.hpp oc_lds): 16-bit index tables of A (& 1) and P (& 2) in its z region of zpad doubles

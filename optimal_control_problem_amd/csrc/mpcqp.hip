@@ -647,14 +647,6 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
   }
   if (h->variant > 0 && !(h->split ? oc_setup_of(h, false) && oc_setup_of(h, true) && oc_admm_of(h, false) && oc_admm_of(h, true) : res_kernel_of(h, false) && res_kernel_of(h, true)))
     return bail(fail(MPCQP_ERR_STATE, "no kernel instance for this handle (kernel_table.hpp)"));
-  if (h->split) {     // the kernel arguments once more in global memory, for code that runs out of line (kernel_oc_split.hpp OcCold)
-    std::vector<OcCold> cold(1);
-    cold[0].pl = h->dp; cold[0].rs = h->dres; cold[0].st = h->st; cold[0].oc = h->doc; cold[0].oc.cold = nullptr;
-    const OcCold *dc = nullptr;
-    int rc = upload(h, cold, &dc);
-    if (rc) return bail(rc);
-    h->doc.cold = dc;
-  }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_mid) != hipSuccess) return bail(fail(MPCQP_ERR_HIP, "hipEventCreate failed"));
   memset(&h->io, 0, sizeof(h->io));
   h->lpt = !getenv("MPCQP_NO_LPT");
@@ -1096,7 +1088,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
     }
     HIPCHK(hipEventRecord(h->pipe_ev[c], cs));
     HIPCHK(hipStreamWaitEvent(s, h->pipe_ev[c], 0));
-    if ((rc = launch_slice(h, io, b0, cnt, s, 1 + c % 15))) return rc;
+    if ((rc = launch_slice(h, io, b0, cnt, s, 1 + c % ns))) return rc;      // (one set of ticket counters per compute stream: the slices of a stream run one after the other)
     if (x) HIPCHK(hipMemcpyAsync(x + (size_t)b0 * n, h->ox + (size_t)b0 * n, (size_t)cnt * n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (y && m) HIPCHK(hipMemcpyAsync(y + (size_t)b0 * m, h->oy + (size_t)b0 * m, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, s));
     if (status) HIPCHK(hipMemcpyAsync(status + b0, h->ostatus + b0, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -319,10 +319,9 @@ inline Plan build_plan(int n, int m, const int *Pp, const int *Pi, const int *Ap
       }
       if (okc) {
         std::vector<int> pos_ds(n, -1);
-        int base = 0, ci = 0, cnt = 0, seg_first = 0;
+        int base = 0;
         std::vector<std::pair<int, int>> segs;      // [first order index, one past the last) of every segment
         for (int i = 0; i <= S; i++) { const int a = i == 0 ? 0 : cuts[i - 1], b = i == S ? nonhub : cuts[i]; segs.push_back({a, b}); }
-        (void)ci; (void)cnt; (void)seg_first;
         for (auto &sg : segs) {
           std::vector<int> mem;
           for (int t = sg.first; t < sg.second; t++) if (!is_sep[t]) mem.push_back(inv[t]);
