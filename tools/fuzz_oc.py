@@ -9,6 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY = sys.argv[3] if len(sys.argv) > 3 else "oc4"
+pairs = {}
 os.environ["MPCQP_VARIANT"] = FAMILY
 import numpy as np
 
@@ -29,6 +30,7 @@ for c in range(ncase):
             skipped += 1; continue
         raise
     assert qp.plan_info()["variant"] == (208 if FAMILY == "oc8" else 204)
+    pairs[qp.oc_info().get("chain_pairs", 1)] = pairs.get(qp.oc_info().get("chain_pairs", 1), 0) + 1
     qp.keep_workspace(True)
     pat = orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai); st = orc.State(pat, B, orc.default_settings())
     q2 = ls.q * 1.2 + 0.05 * rng.normal(size=ls.q.shape); sh = 0.02 * rng.normal(size=ls.l.shape)
@@ -45,5 +47,6 @@ for c in range(ncase):
         else:
             bad += 1; print("MISMATCH %s case %d %s status %s/%s iters %s/%s rel err %.2e" % (tag, c, dims, got["status"], ref["status"], got["iters"], ref["iters"], err))
     qp.close()
+print("patterns by twisted pairs of chains (1 = plain / twisted order, more = the dissected order): %s" % dict(sorted(pairs.items())))
 print("done: %d cases (%d skipped: outside the instance's limits), %d solves at the tight bar, %d tolerance-level, %d mismatches" % (ncase, skipped, tight, soft, bad))
 sys.exit(1 if bad else 0)
