@@ -107,7 +107,7 @@ def test_random_stage_patterns_onchip_families(built, monkeypatch):
     from optimal_control_problem_amd import _lib
     from optimal_control_problem_amd.batch_qp import BatchQP
     from oracle import oracle as orc
-    stats = {f: dict(solves=0, soft=0, cases=0) for f, _ in OC_FAMILIES}
+    stats = {f: dict(solves=0, soft=0, cases=0, dissected=0) for f, _ in OC_FAMILIES}
     worst = 0.0
     for fam, code in OC_FAMILIES:
         monkeypatch.setenv("MPCQP_VARIANT", fam)
@@ -123,6 +123,7 @@ def test_random_stage_patterns_onchip_families(built, monkeypatch):
                 raise
             assert qp.plan_info()["variant"] == code
             stats[fam]["cases"] += 1
+            stats[fam]["dissected"] += qp.oc_info()["chain_pairs"] > 1       # (separators of the stage chain in the hub block: several twisted pairs of chains)
             qp.keep_workspace(True)
             st = orc.State(orc.Pattern(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai), B, orc.default_settings())
             q2 = ls.q * 1.2 + 0.05 * rng.normal(size=ls.q.shape); sh = 0.02 * rng.normal(size=ls.l.shape)
@@ -154,8 +155,9 @@ def test_random_stage_patterns_onchip_families(built, monkeypatch):
                     worst = max(worst, rg / max(ro, 1e-300))
                     assert rg <= max(1.0, 2.0 * ro) * (1 + 1e-9), (tag, b, rg, ro)
             qp.close()
-    report = {f: "%d of %d solves, %d patterns" % (s["soft"], s["solves"], s["cases"]) for f, s in stats.items()}
+    report = {f: "%d of %d solves, %d patterns (%d in the dissected order)" % (s["soft"], s["solves"], s["cases"], s["dissected"]) for f, s in stats.items()}
     print("on-chip families, tolerance-level instances:", report, "worst residual ratio gpu / oracle among them: %.2f" % worst)
     for fam, s in stats.items():
         assert s["cases"] == OC_NPAT, (fam, report)
+        assert 0 < s["dissected"] < s["cases"], (fam, report)        # both orders are in the gate
         assert s["soft"] <= 0.03 * s["solves"], (fam, report)
