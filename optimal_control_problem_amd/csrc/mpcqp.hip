@@ -172,6 +172,16 @@ static const void *oc_admm_of(const mpcqp_handle *h, bool rf = false) {
 // One solve of the two-kernel on-chip mode on stream s: set-up, iteration; then, for instances whose adaptive-rho step asked for a new factor
 // (kernel_oc_split.hpp: they leave the iteration kernel marked OC_PENDING), `resume_rounds` pairs of {re-factorisation, iteration} in which every other
 // workgroup returns at once, and a last pair whose iteration kernel re-factorises in place, so that any number of rho updates is served.
+// The idle waves' L2 touch during the backward chains (kernel_oc_split.hpp idle_touch): off for the eight-wave instances (one QP's sweeps do not fit a CU's share of
+// the L2; MPCQP_TOUCH8 turns it on) and, since round 4, for the four-wave instances of the two-kernel form as well -- with the sweeps' gathers batched and three set-up
+// workgroups per CU the touch only competes with them (quadrotor N=20 x 8192 iteration kernel 5.25 -> 5.15 ms without it, N=15 3.98 -> 3.82, N=10 3.02 -> 2.94;
+// cart-pole N=50 and double integrator N=60 unchanged; MPCQP_TOUCH4 turns it on).  The single-kernel form keeps it.
+static int no_touch_of(const mpcqp_handle *h) {
+  if (getenv("MPCQP_NO_TOUCH")) return 1;
+  if (h->oc8) return getenv("MPCQP_TOUCH8") ? 0 : 1;
+  if (h->split) return getenv("MPCQP_TOUCH4") ? 0 : 1;
+  return 0;
+}
 static int launch_oc_split(mpcqp_handle *h, DevIO &io, int count, bool reuse, hipStream_t s, hipEvent_t after_setup, int qslot) {
   const dim3 grid(count), block(h->variant * WAVE), block_s(h->setup_nw * WAVE);
   // the iteration kernel as resident workgroups that draw instances from one counter (kernel_oc_split.hpp) when the batch is more than the GPU holds at once
@@ -977,7 +987,7 @@ int mpcqp_solve(mpcqp_handle *h, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (h->inner) return solve_reduced(h, s);
   DevIO io = h->io;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = (getenv("MPCQP_NO_TOUCH") || (h->oc8 && !getenv("MPCQP_TOUCH8"))) ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = no_touch_of(h); io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = h->reuse_next ? 1 : 0; io.keep = h->keep ? 1 : 0;
   io.order = (h->lpt && h->order_cur >= 0) ? h->order[h->order_cur] : nullptr;
   if (io.order && h->last_stream != s) HIPCHK(hipStreamWaitEvent(s, h->ev_order, 0));    // the hint was written on another stream
@@ -1067,7 +1077,7 @@ int mpcqp_solve_host(mpcqp_handle *h, const double *P, long sP, const double *q,
   for (int i = 0; i < ns; i++) if (!h->pipe[i]) HIPCHK(hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking));
   DevIO io = h->io;
   io.P = h->dP; io.sP = sP; io.q = h->dq; io.sq = n; io.A = h->dA; io.sA = sA; io.l = h->dl; io.sl = m; io.u = h->du; io.su = m;
-  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = (getenv("MPCQP_NO_TOUCH") || (h->oc8 && !getenv("MPCQP_TOUCH8"))) ? 1 : 0; io.cscale = h->ocs; io.dbg = h->odbg;
+  io.x = h->ox; io.y = h->oy; io.z = h->oz; io.status = h->ostatus; io.iters = h->oiters; io.info = h->oinfo; io.ws = h->ws; io.no_remap = getenv("MPCQP_NO_REMAP") ? 1 : 0; io.no_touch = no_touch_of(h); io.cscale = h->ocs; io.dbg = h->odbg;
   io.reuse = 0; io.keep = h->keep ? 1 : 0; io.order = nullptr;
   if (sP == 0 && wP) HIPCHK(hipMemcpy(h->dP, P, wP * sizeof(double), hipMemcpyHostToDevice));      // shared matrices: once
   if (sA == 0 && wA) HIPCHK(hipMemcpy(h->dA, A, wA * sizeof(double), hipMemcpyHostToDevice));
