@@ -311,8 +311,12 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const long q1 = small_ok && l1 <= LDS_MAX ? LDS_MAX / l1 : 0, q2 = small_ok && l2 <= 40 * 1024 ? std::min<long>(LDS_MAX / l2, 6) : 0;
       auto oc_takes = [&]() {
         if (getenv("MPCQP_NO_OC") || !small_ok) return false;
-        const OcPlan o = build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH);
-        return o.ok && lds_bytes_oc(p4, build_res_plan(p4, 4, false), o) <= OC_LDS_MAX;
+        auto ok4 = [&](const Plan &q) { const OcPlan o = build_oc_plan(q, 4, 1 << 20, OC_NG, OC_NH); return o.ok && lds_bytes_oc(q, build_res_plan(q, 4, false), o) <= OC_LDS_MAX; };
+        if (ok4(p4)) return true;
+        // (the padded twist -- plan.hpp ordering 3 -- where the hub variables would otherwise share a block with the last frame and spill into a second one: cart-pole N=22, 25)
+        if (!twist) return false;
+        const Plan q = build_plan(n, m, Pp, Pi, Ap, Ai, 3, 1);
+        return q.error.empty() && ok4(q);
       };
       if (q2 > cap4 && q2 + 1 >= q1 && !getenv("MPCQP_NO_RES2")) want = 2;
       // the latency regime above; with three or four 4-wave workgroups per CU they stay ahead of one wave per QP up to about three resident
@@ -382,7 +386,19 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
       const ResPlan r4 = build_res_plan(p4, 4, false);
       h->oc = false;
       OcPlan o = small_ok ? build_oc_plan(p4, 4, 1 << 20, OC_NG, OC_NH) : OcPlan();
-      bool dissected4 = false;
+      bool dissected4 = false, padded4 = false;
+      if (small_ok && twist && !getenv("MPCQP_NO_PADTWIST")) {
+        // the padded twist (ordering 3: the hub moved up to a block boundary, the chain part whole blocks) where the plain order is not taken -- the hub shares a
+        // block with the last frame and spills into a second one: cart-pole N=22, 25 fell to the LDS-resident kernel, 18 ms against 12 -- or leaves one long chain
+        // where the twist has two (cart-pole N=24: one chain of 7)
+        Plan q = build_plan(n, m, Pp, Pi, Ap, Ai, 3, 2);
+        if (q.error.empty()) {
+          const OcPlan oq = build_oc_plan(q, 4, 1 << 20, OC_NG, OC_NH);
+          auto longest = [](const OcPlan &x) { return std::max(x.chainE.size(), x.chainF.size()); };
+          const bool fits = oq.ok && lds_bytes_oc(q, build_res_plan(q, 4, false), oq) <= OC_LDS_MAX, o_fits = o.ok && lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX;
+          if (fits && (!o_fits || longest(oq) < longest(o))) { o = oq; p4 = q; padded4 = true; }
+        }
+      }
       if (o.ok && o.has_hub && twist && !getenv("MPCQP_NO_DISSECT") && !getenv("MPCQP_OC_MONO") && !getenv("MPCQP_TILES") && !getenv("MPCQP_VTILES") && !getenv("MPCQP_DOUBLES")) {
         // the dissected order with one separator: two twisted pairs on the four waves (plan.hpp build_plan ordering 4; its own kernel instances, two-kernel form only)
         Plan pd = build_plan(n, m, Pp, Pi, Ap, Ai, 4, 2, 1);
@@ -391,10 +407,10 @@ int mpcqp_create(int n, int m, int batch, const int *Pp, const int *Pi, const in
           if (od.ok && od.pairs.size() == 2 && lds_bytes_oc(pd, build_res_plan(pd, 4, false), od) <= OC_LDS_MAX) { o = od; p4 = pd; dissected4 = true; }
         }
       }
-      if (o.ok && (dissected4 || lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX)) {
+      if (o.ok && (dissected4 || padded4 || lds_bytes_oc(p4, r4, o) <= OC_LDS_MAX)) {
         h->ocplan = o; h->oc = true;
         // same ordering and blocks, ELL widths for this instance's 8 slots in flight (plan.hpp build_ell pad = 2)
-        if (!dissected4 && !getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
+        if (!dissected4 && !padded4 && !getenv("MPCQP_OC_PAD4")) { Plan poc = build_plan(n, m, Pp, Pi, Ap, Ai, twist ? 2 : -1, 2); if (poc.error.empty() && poc.nblk == p4.nblk) p4 = poc; }
       }
       if (!h->oc && want == 4 && variant_request() && std::string(variant_request()) == "oc4")
         return bail(fail(MPCQP_ERR_LIMIT, "the on-chip variant does not take this pattern / size"));
