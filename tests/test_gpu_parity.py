@@ -720,6 +720,23 @@ def test_dissected_order_nonconvex_instance_and_graph_replay(built, monkeypatch)
     assert np.nanmax(np.abs(tw["x"] - got["x"])) < 1e-7
 
 
+@pytest.mark.parametrize("N", [22, 24, 25])
+def test_padded_twist_keeps_awkward_horizons_on_chip(built, N):
+    """horizons at which the hub variables would share a block with the last frame (cart-pole N=22, 25) or the plain order leaves one long chain (N=24): the
+    four-wave on-chip instances take the padded twist (plan.hpp ordering 3) instead of handing the pattern to a slower kernel family -- same bar against the oracle"""
+    from optimal_control_problem_amd.batch_qp import BatchQP
+    mdl, ls, _ = models.make_workload("cartpole", 6000, N=N)          # (a batch large enough for the throughput rule: the small-batch rule has its own choice)
+    qp = BatchQP(ls.n, ls.m, ls.batch, ls.Pp, ls.Pi, ls.Ap, ls.Ai)
+    info = qp.plan_info(); oc = qp.oc_info()
+    assert info["variant"] == 204 and oc["chain_e"] > 0 and oc["chain_f"] > 0, (info, oc)      # on chip, two chains
+    qp.update(ls.P, ls.q, ls.A, ls.l, ls.u); qp.solve(); got = qp.get(); qp.close()
+    sub = type(ls)(ls.n, ls.m, ls.Pp, ls.Pi, ls.Ap, ls.Ai, ls.P[:64], ls.q[:64], ls.A[:64], ls.l[:64], ls.u[:64])
+    ref = problems.oracle_solve(sub)
+    assert (got["status"][:64] == ref["status"]).all() and (got["iters"][:64] == ref["iters"]).all()
+    assert np.abs(got["x"][:64] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+    assert (got["status"] == 1).all()
+
+
 @pytest.mark.parametrize("name,N,B", [("quadrotor", 50, 40), ("quadrotor", 100, 12), ("cartpole", 100, 30)])
 def test_long_horizons_vs_oracle(built, name, N, B):
     """long horizons run the global-block kernels, the longest ones with z and y in the slab as well (one more workgroup per
